@@ -1,0 +1,131 @@
+/*
+ * msm_amd.h -- C ABI of the MI355X multi-scalar-multiplication engine (libmsm_amd.so).
+ *
+ * Drop-in boundary for the reference's WASM export surface (one set per curve x group):
+ *
+ *   reference export (wasmcurves/src/build_multiexp.js)            this library
+ *   ------------------------------------------------------------   -------------------------------------
+ *   g1m_multiexp(pBases,pScalars,scalarSize,n,pr)        :251-257   msm_<curve>_g1m_multiexp
+ *   g1m_multiexpAffine(pBases,pScalars,scalarSize,n,pr)  :251-257   msm_<curve>_g1m_multiexpAffine
+ *   g1m_multiexp_chunk(...,startBit,chunkSize,pr)        :96-104    msm_<curve>_g1m_multiexp_chunk
+ *   g1m_multiexpAffine_chunk(...)                        :96-104    msm_<curve>_g1m_multiexpAffine_chunk
+ *   g2m_* (same four, Fp2 coordinates)                              msm_<curve>_g2m_*
+ *   (wired in wasmcurves/src/build_curve_jacobian_a0.js:1426-1430; <curve> = bls12381 | bn128)
+ *
+ * Data formats are the reference's linear-memory images:
+ *   field element : n8 bytes little-endian, Montgomery form (value * 2^(8*n8) mod q), < q
+ *                   n8 = 48 (bls12381) / 32 (bn128); an Fp2 element is c0 || c1
+ *   affine point  : x || y            ; infinity = all-zero bytes
+ *   Jacobian point: X || Y || Z       ; infinity <=> Z == 0
+ *   scalars       : n * scalar_size bytes, plain little-endian integers (not Montgomery, not
+ *                   reduced mod r; any value < 2^(8*scalar_size)), 1 <= scalar_size <= 64
+ *   output        : one Jacobian point, ALWAYS normalised: (x, y, R) or (0, R, 0) for infinity,
+ *                   i.e. byte-equal to g?m_normalize() of the reference's result
+ *                   (build_curve_jacobian_a0.js:940-973).
+ *
+ * Pointers are host pointers unless the call carries MSM_AMD_DEVICE_PTRS.  The caller owns every
+ * buffer; nothing is retained after return.  The reference functions return void and trap on
+ * bad memory; these return 0 on success or a negative MSM_AMD_E* code (msm_amd_last_error()
+ * gives the text).  n == 0 yields infinity, as build_multiexp.js:283-287 / :119-125.
+ * One context serialises its calls (the reference instance is single-threaded too); use one
+ * context per thread / per GPU.
+ */
+#ifndef MSM_AMD_H
+#define MSM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct msm_amd_ctx msm_amd_ctx;
+
+enum { MSM_AMD_BLS12381 = 0, MSM_AMD_BN128 = 1 };
+
+/* flags */
+enum {
+    MSM_AMD_BASES_JACOBIAN = 1, /* bases are X||Y||Z (g?m_multiexp); default affine x||y (g?m_multiexpAffine) */
+    MSM_AMD_DEVICE_PTRS = 2     /* bases and scalars already live in this context's GPU memory              */
+};
+
+/* error codes */
+enum {
+    MSM_AMD_OK = 0,
+    MSM_AMD_EINVAL = -1,   /* bad argument (null pointer, scalar_size out of range, bad curve/group, misaligned device pointer) */
+    MSM_AMD_EHIP = -2,     /* HIP runtime failure (no GPU, out of memory, launch failure) */
+    MSM_AMD_ENOMEM = -3
+};
+
+/* ---- context ------------------------------------------------------------------------------- */
+int msm_amd_create(int device_id, msm_amd_ctx **out_ctx);
+void msm_amd_destroy(msm_amd_ctx *ctx);
+const char *msm_amd_last_error(const msm_amd_ctx *ctx);
+/* Optional tuning: window size c in bits (0 = automatic). */
+int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
+
+/* ---- generic entry points -------------------------------------------------------------------- */
+/* R = sum_i scalar_i * base_i                                 (build_multiexp.js:251-371) */
+int msm_amd_multiexp(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, const void *scalars,
+                     uint32_t scalar_size, uint32_t n, uint8_t *out);
+/* R = sum_i getChunk(scalar_i, start_bit, chunk_size) * base_i (build_multiexp.js:96-249, :25-94) */
+int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
+                           const void *scalars, uint32_t scalar_size, uint32_t n, uint32_t start_bit,
+                           uint32_t chunk_size, uint8_t *out);
+
+/* ---- multi-GPU: one shard of the Pippenger windows -------------------------------------------- */
+/* Computes the contribution of windows {w : w % nshards == shard} (already weighted by 2^(c*w)),
+ * written as an (un-normalised) Jacobian point.  Summing the nshards partials gives the MSM.      */
+int msm_amd_multiexp_shard(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
+                           const void *scalars, uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards,
+                           uint8_t *out_partial);
+/* out = normalise(sum of `count` Jacobian partials) -- host only, no GPU needed */
+int msm_amd_combine(int curve, int group, const uint8_t *partials, uint32_t count, uint8_t *out);
+
+/* ---- reference-named wrappers (host pointers) ------------------------------------------------- */
+#define MSM_AMD_DECL(curve, g)                                                                                       \
+    int msm_##curve##_##g##_multiexp(msm_amd_ctx *ctx, const uint8_t *bases, const uint8_t *scalars,               \
+                                     uint32_t scalar_size, uint32_t n, uint8_t *out);                              \
+    int msm_##curve##_##g##_multiexpAffine(msm_amd_ctx *ctx, const uint8_t *bases, const uint8_t *scalars,         \
+                                           uint32_t scalar_size, uint32_t n, uint8_t *out);                        \
+    int msm_##curve##_##g##_multiexp_chunk(msm_amd_ctx *ctx, const uint8_t *bases, const uint8_t *scalars,         \
+                                           uint32_t scalar_size, uint32_t n, uint32_t start_bit,                   \
+                                           uint32_t chunk_size, uint8_t *out);                                     \
+    int msm_##curve##_##g##_multiexpAffine_chunk(msm_amd_ctx *ctx, const uint8_t *bases, const uint8_t *scalars,   \
+                                                 uint32_t scalar_size, uint32_t n, uint32_t start_bit,             \
+                                                 uint32_t chunk_size, uint8_t *out);
+MSM_AMD_DECL(bls12381, g1m)
+MSM_AMD_DECL(bls12381, g2m)
+MSM_AMD_DECL(bn128, g1m)
+MSM_AMD_DECL(bn128, g2m)
+#undef MSM_AMD_DECL
+
+/* ---- comparison / conversion helpers the reference's harness uses (host, no GPU) --------------- */
+/* g?m_normalize (build_curve_jacobian_a0.js:940-973), g?m_toAffine (:977-1011), g?m_eq (:173-238) */
+int msm_amd_normalize(int curve, int group, const uint8_t *jac_in, uint8_t *jac_out);
+int msm_amd_to_affine(int curve, int group, const uint8_t *jac_in, uint8_t *aff_out);
+int msm_amd_eq(int curve, int group, const uint8_t *jac_a, const uint8_t *jac_b); /* 1 equal, 0 not, <0 error */
+/* f1m_toMontgomery / f1m_fromMontgomery (build_f1m.js:1089-1110) on `count` base-field elements */
+int msm_amd_f_to_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
+int msm_amd_f_from_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
+
+/* ---- device memory + measurement utilities (bench / tests) ------------------------------------- */
+int msm_amd_dev_alloc(msm_amd_ctx *ctx, size_t bytes, void **dev_ptr);
+int msm_amd_dev_free(msm_amd_ctx *ctx, void *dev_ptr);
+int msm_amd_h2d(msm_amd_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);
+int msm_amd_d2h(msm_amd_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
+/* Fills dev_out with n affine points k_i * G (k_i from a counter-based PRNG of `seed`): synthetic bases. */
+int msm_amd_gen_points(msm_amd_ctx *ctx, int curve, int group, uint64_t seed, uint32_t n, void *dev_out);
+/* Per-stage GPU time of the last call on this context, HIP events on the engine's stream (ms).
+ * Order: [0] total GPU, [1] digits+histogram, [2] scan+order, [3] scatter, [4] bucket accumulation,
+ *        [5] bucket reduction, [6] host combine (wall), [7] bases conversion (Jacobian input only).
+ * Returns the number of entries written. */
+int msm_amd_get_timings(const msm_amd_ctx *ctx, float *ms, int capacity);
+/* Window geometry of the last call: [0] c, [1] windows W, [2] buckets per window, [3] windows processed */
+int msm_amd_get_geometry(const msm_amd_ctx *ctx, uint32_t *out4);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSM_AMD_H */

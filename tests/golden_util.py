@@ -82,3 +82,14 @@ def random_case(curve, group, label, n, scalar_size=32):
     G = golden(curve)["groups"][f"g{group}"]
     idx = indices_for(label, n, G["pool_count"])
     return pool_points(curve, group, idx), scalars_for(curve, label, n, scalar_size)
+
+
+def canon(curve, group, jac_norm, zero):
+    """Canonical form of a *normalised* reference output.  The reference has two byte images for the
+    identity: (0, R, 0) from g?m_zero and (0, 0, R) from addMixed(infinity, affine infinity)
+    (build_curve_jacobian_a0.js:697-704), which all its own operations (incl. g?m_eq) treat alike.
+    The engine always writes (0, R, 0)."""
+    fsz = N8[curve] * group
+    if jac_norm[:2 * fsz] == bytes(2 * fsz) or jac_norm[2 * fsz:] == bytes(fsz):
+        return zero
+    return jac_norm

@@ -1,0 +1,93 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/msm_amd.h declares,
+and its host-only helpers (normalize / toAffine / eq / combine / Montgomery conversion) agree with the
+oracle on the golden data.  No GPU is needed (and none is touched)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import golden_util as gu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "msm_amd.h")
+
+
+@pytest.fixture(scope="module")
+def msm():
+    import msm_amd
+    msm_amd.load_library()
+    return msm_amd
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    names = set(re.findall(r"\b(msm_amd_[a-z0-9_]+)\s*\(", src))
+    for curve in ("bls12381", "bn128"):
+        for g in ("g1m", "g2m"):
+            for fn in ("multiexp", "multiexpAffine", "multiexp_chunk", "multiexpAffine_chunk"):
+                names.add(f"msm_{curve}_{g}_{fn}")
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(msm):
+    L = msm.load_library()
+    names = declared_symbols()
+    assert len(names) >= 16 + 18
+    for name in names:
+        assert hasattr(L, name), f"libmsm_amd.so does not export {name}"
+
+
+def test_missing_library_fails_loudly(msm, tmp_path):
+    import importlib
+    saved = msm._lib
+    try:
+        msm._lib = None
+        with pytest.raises(msm.MsmAmdError):
+            msm.load_library(str(tmp_path / "nope.so"))
+    finally:
+        msm._lib = saved
+
+
+def test_create_without_gpu_is_an_error_not_a_fallback(msm):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(msm.MsmAmdError):
+        msm.Engine(0)
+
+
+@pytest.mark.parametrize("curve", ["bls12381", "bn128"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_host_helpers_match_oracle(msm, oracle_lib, curve, group):
+    O = oracle_lib.Oracle(curve, group)
+    G = gu.golden(curve)["groups"][f"g{group}"]
+    pts = []
+    for rec in G["groupops"]:
+        raw = bytes.fromhex(rec["out_raw"])
+        pts.append(raw)
+        assert msm.normalize(curve, group, raw) == gu.canon(curve, group, bytes.fromhex(rec["out_norm"]), O.zero())
+        assert msm.to_affine(curve, group, raw) == O.to_affine(raw)
+        assert msm.eq(curve, group, raw, bytes.fromhex(rec["out_norm"]))
+    # eq is false for different points
+    a, b = bytes.fromhex(G["groupops"][0]["out_raw"]), bytes.fromhex(G["groupops"][1]["out_raw"])
+    assert msm.eq(curve, group, a, b) == O.eq(a, b)
+    # combine == chained oracle adds
+    acc = O.zero()
+    for p in pts:
+        acc = O.add(acc, p)
+    assert msm.combine(curve, group, b"".join(pts)) == gu.canon(curve, group, O.normalize(acc), O.zero())
+    assert msm.combine(curve, group, b"") == O.zero()
+
+
+@pytest.mark.parametrize("curve", ["bls12381", "bn128"])
+def test_montgomery_conversion_matches_reference(msm, curve):
+    G = gu.golden(curve)["groups"]["g1"]
+    n = 0
+    for rec in G["fieldops"]:
+        if "to_montgomery" in rec:
+            x = bytes.fromhex(rec["x"])
+            assert msm.f_to_montgomery(curve, x).hex() == rec["to_montgomery"]
+            assert msm.f_from_montgomery(curve, x).hex() == rec["from_montgomery"]
+            n += 1
+    assert n >= 10

@@ -1,0 +1,209 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP engine, called through the C ABI,
+against (a) the committed golden vectors produced by the reference WASM, (b) the CPU oracle on seeded
+inputs, (c) size-independent properties at the BASELINE sizes.  Integer work: the bar is bit-exact
+equality of the normalised Jacobian bytes."""
+import os
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+CURVES = ["bls12381", "bn128"]
+GROUPS = [1, 2]
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import msm_amd
+    e = msm_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(oracle_lib):
+    return oracle_lib
+
+
+def _fn(C, group, affine, chunk=False):
+    name = f"g{group}m_multiexp" + ("Affine" if affine else "") + ("_chunk" if chunk else "")
+    return getattr(C, name)
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("group", GROUPS)
+def test_golden_vectors(eng, orc, curve, group):
+    """Every golden MSM record (random, edge classes, scalar sizes, Jacobian bases) incl. _chunk outputs."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    zero = O.zero()
+    for rec in gu.golden(curve)["groups"][f"g{group}"]["msm"]:
+        bases, scalars = gu.msm_inputs(curve, group, rec)
+        affine = rec["fn"] == "multiexpAffine"
+        out = _fn(C, group, affine)(bases, scalars, rec["scalar_size"], rec["n"])
+        assert out == gu.canon(curve, group, bytes.fromhex(rec["out_norm"]), zero), rec["id"]
+        for ch in rec.get("chunks", []):
+            o = _fn(C, group, affine, True)(bases, scalars, rec["scalar_size"], rec["n"], ch["start_bit"], ch["chunk_size"])
+            assert o == gu.canon(curve, group, bytes.fromhex(ch["out_norm"]), zero), (rec["id"], ch["start_bit"], ch["chunk_size"])
+
+
+@pytest.mark.parametrize("curve", CURVES)
+@pytest.mark.parametrize("group", GROUPS)
+@pytest.mark.parametrize("c", [0, 1, 2, 5, 9, 13])
+def test_window_size_independence(eng, orc, curve, group, c):
+    """The window schedule is not part of the contract: every window size gives the reference's answer."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    rec = [r for r in gu.golden(curve)["groups"][f"g{group}"]["msm"] if r["id"] == "rand_n64"][0]
+    bases, scalars = gu.msm_inputs(curve, group, rec)
+    eng.set_window_bits(c)
+    try:
+        out = _fn(C, group, True)(bases, scalars, 32, 64)
+        assert out == bytes.fromhex(rec["out_norm"])
+        assert eng.geometry()["c"] == (c if c else eng.geometry()["c"])
+    finally:
+        eng.set_window_bits(0)
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 5000), ("bls12381", 1, 16384), ("bn128", 1, 16384),
+                                           ("bls12381", 2, 3000), ("bn128", 2, 3000)])
+def test_oracle_seeded(eng, orc, curve, group, n):
+    """Seeded inputs drawn from the committed pool; expected value from the CPU oracle."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, scalars = gu.random_case(curve, group, f"gpu:{curve}:{group}:{n}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    assert _fn(C, group, True)(bases, scalars, 32, n) == exp
+    # a few windows through the _chunk entry point
+    for start, cs in [(0, 13), (247, 13), (100, 7)]:
+        e = O.normalize(O.multiexp_chunk(bases, scalars, 32, n, start, cs))
+        assert _fn(C, group, True, True)(bases, scalars, 32, n, start, cs) == gu.canon(curve, group, e, O.zero())
+
+
+def test_reference_kats(eng, orc):
+    import json
+    with open(os.path.join(gu.GOLDEN, "kats_sum_of_squares.json")) as f:
+        kats = json.load(f)
+    for k in kats["cases"]:
+        C = eng.curve(k["curve"])
+        out = _fn(C, k["group"], True)(bytes.fromhex(k["bases"]), bytes.fromhex(k["scalars"]), k["scalar_size"], k["n"])
+        assert out.hex() == k["expect_norm"]
+    with open(os.path.join(gu.GOLDEN, "kats_batchaffine.json")) as f:
+        k = json.load(f)["multiexp_case1"]
+    import msm_amd
+    plain = b"".join(int(h, 16).to_bytes(48, "little") for h in k["points_affine_plain"])
+    bases = msm_amd.f_to_montgomery("bls12381", plain)
+    scalars = b"".join(int(h, 16).to_bytes(32, "little") for h in k["scalars"])
+    out = eng.curve("bls12381").g1m_multiexp_multiExp(bases, scalars, 10)    # opt-path signature
+    aff = msm_amd.f_from_montgomery("bls12381", msm_amd.to_affine("bls12381", 1, out))
+    assert [hex(int.from_bytes(aff[:48], "little")), hex(int.from_bytes(aff[48:], "little"))] == k["expected_affine_plain"]
+
+
+def test_adversarial_single_bucket(eng, orc):
+    """All scalars equal: every pair lands in one bucket per window (maximal imbalance, P+P chains)."""
+    curve, group, n = "bls12381", 1, 2048
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, _ = gu.random_case(curve, group, "gpu:adv", n)
+    s = gu.scalars_for(curve, "gpu:adv:one", 1)
+    scalars = s * n
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp
+    # all points equal as well
+    bases2 = bases[:96] * n
+    exp2 = O.normalize(O.multiexp_affine(bases2, scalars, 32, n))
+    assert C.g1m_multiexpAffine(bases2, scalars, 32, n) == exp2
+
+
+def test_error_codes(eng):
+    import msm_amd
+    C = eng.curve("bls12381")
+    with pytest.raises(msm_amd.MsmAmdError):
+        C.g1m_multiexpAffine(b"\0" * 96, b"\0" * 65, 65, 1)       # scalar_size > 64
+    with pytest.raises(msm_amd.MsmAmdError):
+        C.g1m_multiexpAffine_chunk(b"\0" * 96, b"\0" * 32, 32, 1, 0, 26)   # chunk_size > 25
+    with pytest.raises(msm_amd.MsmAmdError):
+        eng.curve("nope")
+    assert C.g1m_multiexpAffine(b"", b"", 32, 0) == msm_amd.combine("bls12381", 1, b"")    # n = 0 -> infinity
+
+
+@pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 1), ("bls12381", 2), ("bn128", 2)])
+def test_generated_points_are_multiples_of_generator(eng, orc, curve, group):
+    """msm_amd_gen_points (synthetic bench input): P_i = k_i * G with k_i from splitmix64."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    seed, n = 1234, 300
+    buf = C.gen_points(group, seed, n)
+    pts = buf.download(n * C.affine_bytes(group))
+    buf.free()
+    M = (1 << 64) - 1
+
+    def sm(x):
+        x = (x + 0x9E3779B97F4A7C15) & M
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+        return x ^ (x >> 31)
+    gen = bytes.fromhex(gu.golden(curve)["groups"][f"g{group}"]["generator_jacobian"])
+    asz = C.affine_bytes(group)
+    for i in (0, 1, 63, 64, 299):
+        k = [sm((seed * 0x100000001B3 + i * 4 + j) & M) for j in range(4)]
+        k[3] &= 0x3fffffffffffffff
+        kv = k[0] | (k[1] << 64) | (k[2] << 128) | (k[3] << 192)
+        exp = O.to_affine(O.times_scalar(gen, kv.to_bytes(32, "little")))
+        assert pts[i * asz:(i + 1) * asz] == exp, i
+
+
+def _rand_scalars(n, nbytes, seed):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    a[:, nbytes:] = 0
+    return a
+
+
+@pytest.mark.parametrize("curve,group,logn", [("bls12381", 1, 20), ("bn128", 1, 20), ("bls12381", 2, 18)])
+def test_full_size_properties(eng, orc, curve, group, logn):
+    """BASELINE-size checks that need no oracle run: linearity in the scalars, slice additivity,
+    window (chunk) decomposition, and an oracle spot check on a 2^11 slice of the same inputs."""
+    import msm_amd
+    import numpy as np
+    n = 1 << logn
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    asz = C.affine_bytes(group)
+    pts = C.gen_points(group, 77, n)
+    s = _rand_scalars(n, 31, 1)
+    t = _rand_scalars(n, 31, 2)
+    # s + t as 256-bit integers (31-byte operands: no overflow)
+    carry = np.zeros(n, dtype=np.uint16)
+    u = np.zeros_like(s)
+    for b in range(32):
+        v = s[:, b].astype(np.uint16) + t[:, b].astype(np.uint16) + carry
+        u[:, b] = (v & 0xFF).astype(np.uint8)
+        carry = v >> 8
+    ds, dt, du = (eng.alloc(n * 32).upload(x.tobytes()) for x in (s, t, u))
+    f = _fn(C, group, True)
+    Rs, Rt, Ru = f(pts, ds, 32, n), f(pts, dt, 32, n), f(pts, du, 32, n)
+    assert msm_amd.combine(curve, group, Rs + Rt) == Ru                    # linearity
+    # slice additivity
+    half = n // 2
+    host_pts = pts.download(n * asz)
+    lo = f(host_pts[:half * asz], s[:half].tobytes(), 32, half)
+    hi = f(host_pts[half * asz:], s[half:].tobytes(), 32, n - half)
+    assert msm_amd.combine(curve, group, lo + hi) == Rs
+    # oracle spot check on a slice
+    m = 2048
+    exp = O.normalize(O.multiexp_affine(host_pts[:m * asz], s[:m].tobytes(), 32, m))
+    assert f(host_pts[:m * asz], s[:m].tobytes(), 32, m) == exp
+    # window decomposition through the _chunk entry point: sum_w 2^(16 w) chunk_w == full (host Horner via oracle ops)
+    fc = _fn(C, group, True, True)
+    acc = O.zero()
+    for w in range(15, -1, -1):
+        for _ in range(16):
+            acc = O.double(acc)
+        acc = O.add(acc, fc(pts, ds, 32, n, 16 * w, 16))
+    assert O.normalize(acc) == Rs
+    for b in (ds, dt, du, pts):
+        b.free()

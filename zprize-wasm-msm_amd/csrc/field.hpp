@@ -1,0 +1,294 @@
+// field.hpp -- Montgomery prime-field and quadratic-extension arithmetic for gfx950 (and host).
+//
+// Replaces, on the device, the reference's WASM field layer:
+//   wasmcurves/src/build_f1m.js  (f1m_add :71-89, f1m_sub :91-105, f1m_neg :107-117,
+//                                 f1m_mul :466-777, f1m_square :779-1076, isOne :1318-1327)
+//   wasmcurves/src/build_f2m.js  (f2m_mul :152-188, f2m_square :211-252, add/sub/neg :34-112)
+//   wasmcurves/src/build_int.js  (int_add :186-228, int_sub :232-277, int_gte :148-181)
+// Same value semantics: elements are n32 little-endian 32-bit limbs in Montgomery form with
+// R = 2^(32*N), every result fully reduced to [0, q).  The byte image of an element is therefore
+// identical to the reference's linear-memory image.
+//
+// Device multiplier: product-scanning Montgomery on 32-bit limbs.  v_mad_u64_u32 issues at full
+// rate on gfx950 (profiles/r01_valu_rates_microbench.txt), so one instruction does a 32x32
+// multiply and a 64-bit accumulate; its carry-out is folded into a third accumulator word with
+// one v_addc_co_u32.  The host build of the same templates uses portable 64-bit C.
+#pragma once
+#include <cstdint>
+#include <hip/hip_runtime.h>
+
+#include "params_gen.hpp"
+
+#define MSM_HD __host__ __device__ __forceinline__
+#define MSM_D __device__ __forceinline__
+
+namespace msm {
+
+// (hi:lo) += a*b, 96-bit accumulator
+MSM_HD void mac(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "v"(b)
+        : "vcc");
+#else
+    uint64_t p = (uint64_t)a * b;
+    lo += p;
+    hi += (lo < p);
+#endif
+}
+// same with b a wave-uniform constant kept in an SGPR
+MSM_HD void mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(lo), "+v"(hi)
+        : "v"(a), "s"(b)
+        : "vcc");
+#else
+    mac(lo, hi, a, b);
+#endif
+}
+
+template <class P>
+struct Fp {
+    static constexpr int N = P::N;
+    static constexpr int BYTES = 4 * P::N;
+    using Params = P;
+    uint32_t v[N];
+
+    MSM_HD static Fp zero() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = 0;
+        return r;
+    }
+    MSM_HD static Fp one() {
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = P::ONE[i];
+        return r;
+    }
+    MSM_HD bool is_zero() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o |= v[i];
+        return o == 0;
+    }
+    MSM_HD bool is_one() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o |= v[i] ^ P::ONE[i];
+        return o == 0;
+    }
+    MSM_HD static bool eq(const Fp& a, const Fp& b) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o |= a.v[i] ^ b.v[i];
+        return o == 0;
+    }
+
+    // r = a - q if a >= q else a   (a < 2q, carry = bit 32N of a)
+    MSM_HD static Fp reduce_once(const Fp& a, uint32_t carry) {
+        Fp d;
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)a.v[i] - P::Q[i] - br;
+            d.v[i] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        bool use_d = (carry != 0) || (br == 0);
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = use_d ? d.v[i] : a.v[i];
+        return r;
+    }
+
+    // build_f1m.js:71-89
+    MSM_HD static Fp add(const Fp& a, const Fp& b) {
+        Fp s;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
+            s.v[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+        return reduce_once(s, (uint32_t)c);
+    }
+    MSM_HD static Fp dbl(const Fp& a) { return add(a, a); }
+    // build_f1m.js:91-105
+    MSM_HD static Fp sub(const Fp& a, const Fp& b) {
+        Fp d;
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+            d.v[i] = (uint32_t)t;
+            br = (t >> 32) & 1;
+        }
+        uint32_t mask = (uint32_t)0 - (uint32_t)br;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            uint64_t t = (uint64_t)d.v[i] + (P::Q[i] & mask) + c;
+            d.v[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+        return d;
+    }
+    // build_f1m.js:107-117 (0 - x; neg(0) == 0)
+    MSM_HD static Fp neg(const Fp& a) { return sub(zero(), a); }
+    MSM_HD static Fp cneg(const Fp& a, bool flag) {
+        Fp n = neg(a);
+        Fp r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = flag ? n.v[i] : a.v[i];
+        return r;
+    }
+
+    // build_f1m.js:466-777 -- Montgomery product a*b*R^-1 mod q, fully reduced.
+    MSM_HD static Fp mul_inl(const Fp& a, const Fp& b) {
+        uint32_t m[N];
+        Fp r;
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+#pragma unroll
+            for (int i = 0; i <= k; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = 0; i < k; ++i) mac_s(lo, hi, m[i], P::Q[k - i]);
+            m[k] = (uint32_t)lo * P::NP32;
+            mac_s(lo, hi, m[k], P::Q[0]);
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+#pragma unroll
+        for (int k = N; k < 2 * N; ++k) {
+#pragma unroll
+            for (int i = k - N + 1; i < N; ++i) mac(lo, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+            for (int i = k - N + 1; i < N; ++i) mac_s(lo, hi, m[i], P::Q[k - i]);
+            r.v[k - N] = (uint32_t)lo;
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        return reduce_once(r, (uint32_t)lo);
+    }
+    // build_f1m.js:779-1076 -- square: off-diagonal products computed once and doubled.
+    MSM_HD static Fp sqr_inl(const Fp& a) {
+        uint32_t m[N];
+        Fp r;
+        uint64_t lo = 0;   // running (reduction + carry) accumulator
+        uint32_t hi = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * N; ++k) {
+            // off-diagonal sum for this column: sum_{i<j, i+j=k} a_i a_j
+            uint64_t slo = 0;
+            uint32_t shi = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                int j = k - i;
+                if (j > i && j < N) mac(slo, shi, a.v[i], a.v[j]);
+            }
+            // double it and add to the running accumulator
+            uint32_t s0 = (uint32_t)slo, s1 = (uint32_t)(slo >> 32);
+            uint32_t d0 = s0 << 1, d1 = (s1 << 1) | (s0 >> 31), d2 = (shi << 1) | (s1 >> 31);
+            uint64_t t = (uint64_t)(uint32_t)lo + d0;
+            uint32_t l0 = (uint32_t)t;
+            t = (t >> 32) + (uint32_t)(lo >> 32) + d1;
+            uint32_t l1 = (uint32_t)t;
+            hi = hi + d2 + (uint32_t)(t >> 32);
+            lo = ((uint64_t)l1 << 32) | l0;
+            if ((k & 1) == 0) mac(lo, hi, a.v[k / 2], a.v[k / 2]);
+            if (k < N) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) mac_s(lo, hi, m[i], P::Q[k - i]);
+                m[k] = (uint32_t)lo * P::NP32;
+                mac_s(lo, hi, m[k], P::Q[0]);
+            } else {
+#pragma unroll
+                for (int i = k - N + 1; i < N; ++i) mac_s(lo, hi, m[i], P::Q[k - i]);
+                r.v[k - N] = (uint32_t)lo;
+            }
+            lo = (lo >> 32) | ((uint64_t)hi << 32);
+            hi = 0;
+        }
+        return reduce_once(r, (uint32_t)lo);
+    }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Out-of-line on the device: one ~5 KB body shared by every call site keeps the bucket
+    // kernels inside the instruction cache.
+    __device__ __noinline__ static Fp mul(Fp a, Fp b) { return mul_inl(a, b); }
+    __device__ __noinline__ static Fp sqr(Fp a) { return sqr_inl(a); }
+#else
+    static Fp mul(const Fp& a, const Fp& b) { return mul_inl(a, b); }
+    static Fp sqr(const Fp& a) { return sqr_inl(a); }
+#endif
+
+    // x^(q-2); used only off the hot path (normalisation, batched affine conversion)
+    MSM_HD static Fp inv(const Fp& x) {
+        Fp acc = one();
+        Fp base = x;
+        for (int i = 0; i < 32 * N; ++i) {
+            if ((P::QM2[i >> 5] >> (i & 31)) & 1) acc = mul(acc, base);
+            base = sqr(base);
+        }
+        return acc;
+    }
+    // build_f1m.js:1089-1110
+    MSM_HD static Fp to_mont(const Fp& x) {
+        Fp r2;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r2.v[i] = P::R2[i];
+        return mul(x, r2);
+    }
+    MSM_HD static Fp from_mont(const Fp& x) {
+        Fp o = zero();
+        o.v[0] = 1;
+        return mul(x, o);
+    }
+};
+
+// Fp2 = Fp[u]/(u^2 + 1): both reference curves pass mulNonResidueFn = "f1m_neg"
+// (bls12381/build_bls12381.js:48, bn128/build_bn128.js:43).
+template <class P>
+struct Fp2 {
+    using B = Fp<P>;
+    using Params = P;
+    static constexpr int BYTES = 2 * B::BYTES;
+    B c0, c1;
+
+    MSM_HD static Fp2 zero() { return {B::zero(), B::zero()}; }
+    MSM_HD static Fp2 one() { return {B::one(), B::zero()}; }
+    MSM_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
+    MSM_HD bool is_one() const { return c0.is_one() && c1.is_zero(); }   // build_f2m.js:432-449
+    MSM_HD static bool eq(const Fp2& a, const Fp2& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+    MSM_HD static Fp2 add(const Fp2& a, const Fp2& b) { return {B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    MSM_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
+    MSM_HD static Fp2 sub(const Fp2& a, const Fp2& b) { return {B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    MSM_HD static Fp2 neg(const Fp2& a) { return {B::neg(a.c0), B::neg(a.c1)}; }
+    MSM_HD static Fp2 cneg(const Fp2& a, bool f) { return {B::cneg(a.c0, f), B::cneg(a.c1, f)}; }
+    // build_f2m.js:152-188 (Karatsuba, 3 base multiplications)
+    MSM_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
+        B A = B::mul(a.c0, b.c0);
+        B Bb = B::mul(a.c1, b.c1);
+        B C = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
+        return {B::sub(A, Bb), B::sub(C, B::add(A, Bb))};
+    }
+    // build_f2m.js:211-252: (c0+c1)(c0-c1), 2 c0 c1
+    MSM_HD static Fp2 sqr(const Fp2& a) {
+        B ab = B::mul(a.c0, a.c1);
+        B r0 = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
+        return {r0, B::add(ab, ab)};
+    }
+    // build_f2m.js:378-408
+    MSM_HD static Fp2 inv(const Fp2& a) {
+        B t = B::inv(B::add(B::sqr(a.c0), B::sqr(a.c1)));
+        return {B::mul(a.c0, t), B::neg(B::mul(a.c1, t))};
+    }
+};
+
+}  // namespace msm

@@ -1,0 +1,946 @@
+// msm_engine.hip -- MI355X (gfx950) Pippenger multi-scalar multiplication behind the C ABI of
+// include/msm_amd.h.
+//
+// What the reference does (wasmcurves/src/build_multiexp.js): for each c-bit window, walk the n
+// (scalar, base) pairs sequentially, add each base into table[digit-1] with g1m_addMixed
+// (:186-233), collapse the table by recursive halving (:373-461), and Horner-combine the windows
+// (:310-369).  One thread, unsigned digits, table in WASM linear memory.
+//
+// What this engine does instead (same group element, different schedule):
+//   1. digits      one thread per scalar: signed radix-2^c recoding of the requested bit range
+//                  (digit in [-2^(c-1), 2^(c-1)]), histogram of bucket populations
+//   2. scan/order  exclusive scan of the histogram; buckets ordered by population so that the
+//                  64 lanes of a wavefront run the same trip count
+//   3. scatter     radix-c bucket scatter: point indices (sign in bit 31) grouped by bucket
+//   4. accumulate  one lane per bucket: gather affine points, XYZZ mixed additions (curve.hpp)
+//   5. reduce      per window sum_k k*B_k: short running sums per lane, a small scalar
+//                  multiplication by the lane's bucket offset, LDS tree reduction per workgroup
+//   6. combine     window partials (a few KB) go to the host, which Horner-combines them and
+//                  normalises the result (the serial doubling chain is latency-, not throughput-bound)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msm_amd.h"
+#include "curve.hpp"
+
+namespace msm {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+template <class T>
+MSM_D T load16(const void* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+    T t;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&t);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) {
+        uint4 q = s[k];
+        d[4 * k + 0] = q.x;
+        d[4 * k + 1] = q.y;
+        d[4 * k + 2] = q.z;
+        d[4 * k + 3] = q.w;
+    }
+    return t;
+}
+template <class T>
+MSM_D void store16(void* p, const T& t) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+    uint4* s = reinterpret_cast<uint4*>(p);
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(&t);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) s[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+}
+
+// Window geometry shared by host and kernels.
+struct Geom {
+    uint32_t n;
+    uint32_t scalar_size;   // bytes per scalar
+    uint32_t bit_lo;        // first bit of the scalar range
+    uint32_t nbits;         // bits in the range (after clipping to the scalar end)
+    uint32_t c;             // window bits
+    uint32_t W;             // number of windows = nbits / c + 1 (the last one absorbs the carry)
+    uint32_t half;          // buckets per window = 2^(c-1)
+    uint32_t shard, nshards;   // this call owns windows w with w % nshards == shard
+    uint32_t Wl;            // number of owned windows
+};
+
+// Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
+MSM_D uint32_t scalar_bits(const uint8_t* scalars, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
+    if (nb == 0) return 0;
+    const uint8_t* s = scalars + (size_t)i * g.scalar_size;
+    uint32_t byte = pos >> 3;
+    uint64_t w = 0;
+#pragma unroll
+    for (int b = 0; b < 5; ++b)
+        if (byte + b < g.scalar_size) w |= (uint64_t)s[byte + b] << (8 * b);
+    return (uint32_t)(w >> (pos & 7)) & ((1u << nb) - 1u);
+}
+// fast path: scalar_size % 4 == 0 and 4-byte aligned scalars
+MSM_D uint32_t scalar_bits32(const uint32_t* scalars32, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
+    if (nb == 0) return 0;
+    uint32_t words = g.scalar_size >> 2;
+    const uint32_t* s = scalars32 + (size_t)i * words;
+    uint32_t wi = pos >> 5;
+    uint32_t w0 = s[wi];
+    uint32_t w1 = (wi + 1 < words) ? s[wi + 1] : 0u;
+    uint64_t w = ((uint64_t)w1 << 32) | w0;
+    return (uint32_t)(w >> (pos & 31)) & ((1u << nb) - 1u);
+}
+
+// Signed radix-2^c recoding of scalar i; calls f(window, bucket_in_window (0-based), negative).
+template <bool FAST, class Fn>
+MSM_D void for_each_digit(const uint8_t* scalars, const Geom& g, uint32_t i, Fn&& f) {
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < g.W; ++w) {
+        uint32_t off = w * g.c;
+        uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
+        uint32_t raw = FAST ? scalar_bits32(reinterpret_cast<const uint32_t*>(scalars), g, i, g.bit_lo + off, nb)
+                            : scalar_bits(scalars, g, i, g.bit_lo + off, nb);
+        raw += carry;
+        bool negd = raw > g.half;
+        uint32_t mag = negd ? (1u << g.c) - raw : raw;
+        carry = negd ? 1u : 0u;
+        if (mag != 0 && (w % g.nshards) == g.shard) f(w / g.nshards, mag - 1, negd);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 1 / 3: histogram and scatter
+// ------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_histogram(const uint8_t* __restrict__ scalars, Geom g, uint32_t* __restrict__ count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    for_each_digit<FAST>(scalars, g, i, [&](uint32_t wl, uint32_t b, bool) { atomicAdd(&count[wl * g.half + b], 1u); });
+}
+
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ scalars, Geom g, uint32_t* __restrict__ cursor,
+                                                  uint32_t* __restrict__ sorted) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    for_each_digit<FAST>(scalars, g, i, [&](uint32_t wl, uint32_t b, bool negd) {
+        uint32_t pos = atomicAdd(&cursor[wl * g.half + b], 1u);
+        sorted[pos] = i | (negd ? 0x80000000u : 0u);
+    });
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 2: exclusive scan of bucket populations (three small kernels) and ordering by population
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 16;                       // per thread
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;   // 4096 per workgroup
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t red[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < nb) s += count[base + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = SCAN_BLOCK / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0];
+}
+// single workgroup: in-place exclusive scan of the tile sums
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(uint32_t* __restrict__ tile_sums, uint32_t ntiles) {
+    __shared__ uint32_t buf[SCAN_BLOCK];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < ntiles; start += SCAN_BLOCK) {
+        uint32_t idx = start + threadIdx.x;
+        uint32_t v = idx < ntiles ? tile_sums[idx] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+            uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        uint32_t incl = buf[threadIdx.x];
+        if (idx < ntiles) tile_sums[idx] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == SCAN_BLOCK - 1) carry += incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ count, uint32_t nb, const uint32_t* __restrict__ tile_sums,
+                                                            uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t buf[SCAN_BLOCK];
+    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t loc[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        loc[k] = (base + k < nb) ? count[base + k] : 0;
+        s += loc[k];
+    }
+    buf[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
+        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = tile_sums[blockIdx.x] + buf[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < nb) {
+            offset[base + k] = run;
+            cursor[base + k] = run;
+        }
+        run += loc[k];
+    }
+}
+
+// Ordering of buckets by population (descending), counting sort on min(count, ORDER_BINS-1).
+constexpr int ORDER_BINS = 1024;
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t h[ORDER_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
+        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));   // big buckets first
+        atomicAdd(&h[cls], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ bins) {
+    __shared__ uint32_t buf[ORDER_BINS];
+    uint32_t v = bins[threadIdx.x];
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < ORDER_BINS; d <<= 1) {
+        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    bins[threadIdx.x] = buf[threadIdx.x] - v;
+}
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ bins,
+                                                         uint32_t* __restrict__ order) {
+    __shared__ uint32_t h[ORDER_BINS];
+    __shared__ uint32_t basep[ORDER_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    // each workgroup owns a contiguous span of buckets
+    uint32_t per = (nb + gridDim.x - 1) / gridDim.x;
+    uint32_t lo = blockIdx.x * per, hi = min(nb, lo + per);
+    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
+        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));
+        atomicAdd(&h[cls], 1u);
+    }
+    __syncthreads();
+    basep[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[threadIdx.x], h[threadIdx.x]) : 0;
+    __syncthreads();
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
+        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));
+        uint32_t p = basep[cls] + atomicAdd(&h[cls], 1u);
+        order[p] = b;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 4: bucket accumulation -- one lane per bucket
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                     const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
+                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    uint32_t b = order[r];
+    uint32_t cnt = count[b];
+    uint32_t off = offset[b];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t e = sorted[off + k];
+        uint32_t idx = e & 0x7fffffffu;
+        Affine<F> p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
+        bool inf = p.is_inf();
+        p.y = F::cneg(p.y, (e >> 31) != 0 && !inf);
+        XYZZ<F>::madd(acc, p.x, p.y);
+    }
+    store16(buckets + (size_t)b * sizeof(XYZZ<F>), acc);
+}
+
+// ------------------------------------------------------------------------------------------
+// stage 5: bucket reduction  S_w = sum_{k=1..half} k * B[w][k-1]
+// Lane t of window w owns buckets [t*L, t*L+L): running sums give sum_j (j+1) B[t*L+j] and
+// A = sum_j B[t*L+j]; adding (t*L)*A (double-and-add) makes the lane's share exact; a workgroup
+// tree in LDS then leaves one partial per workgroup.
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
+                                                        uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    uint32_t w = blockIdx.x / wgs_per_window;
+    uint32_t wg = blockIdx.x % wgs_per_window;
+    uint32_t t = wg * blockDim.x + threadIdx.x;
+    XYZZ<F> res = XYZZ<F>::inf();
+    if (t < lanes_per_window) {
+        uint32_t base = t * L;
+        XYZZ<F> run = XYZZ<F>::inf();
+        XYZZ<F> sum = XYZZ<F>::inf();
+        for (int j = (int)L - 1; j >= 0; --j) {
+            if (base + j < half) {
+                XYZZ<F> bk = load16<XYZZ<F>>(buckets + ((size_t)w * half + base + j) * sizeof(XYZZ<F>));
+                run = XYZZ<F>::add(run, bk);
+            }
+            sum = XYZZ<F>::add(sum, run);
+        }
+        // res = sum + base * run
+        XYZZ<F> m = XYZZ<F>::inf();
+        if (base != 0) {
+            int top = 31 - __clz(base);
+            for (int bit = top; bit >= 0; --bit) {
+                m = XYZZ<F>::dbl(m);
+                if ((base >> bit) & 1u) m = XYZZ<F>::add(m, run);
+            }
+        }
+        res = XYZZ<F>::add(sum, m);
+    }
+    sh[threadIdx.x] = res;
+    __syncthreads();
+    for (int d = blockDim.x / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            XYZZ<F> a = sh[threadIdx.x];
+            XYZZ<F> bb = sh[threadIdx.x + d];
+            sh[threadIdx.x] = XYZZ<F>::add(a, bb);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store16(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>), sh[0]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Jacobian bases -> affine (g?m_multiexp entry point): Montgomery's trick, 8 points per lane
+// (build_curve_jacobian_a0.js:1040-1125 batchToAffine does the same thing sequentially).
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __restrict__ jac, uint32_t n, uint8_t* __restrict__ aff) {
+    constexpr int K = 8;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t first = t * K;
+    if (first >= n) return;
+    F pref[K];
+    F acc = F::one();
+    for (int k = 0; k < K; ++k) {
+        uint32_t i = first + k;
+        pref[k] = acc;
+        if (i < n) {
+            F z = load16<F>(jac + (size_t)i * 3 * sizeof(F) + 2 * sizeof(F));
+            if (!z.is_zero()) acc = F::mul(acc, z);
+        }
+    }
+    F inv = F::inv(acc);
+    for (int k = K - 1; k >= 0; --k) {
+        uint32_t i = first + k;
+        if (i >= n) continue;
+        Jacobian<F> p = load16<Jacobian<F>>(jac + (size_t)i * sizeof(Jacobian<F>));
+        Affine<F> a;
+        if (p.z.is_zero()) {
+            a = {F::zero(), F::zero()};
+        } else {
+            F zi = F::mul(inv, pref[k]);
+            inv = F::mul(inv, p.z);
+            F zi2 = F::sqr(zi);
+            a.x = F::mul(p.x, zi2);
+            a.y = F::mul(p.y, F::mul(zi2, zi));
+        }
+        store16(aff + (size_t)i * sizeof(Affine<F>), a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// synthetic bases for benchmarks/tests: P_i = k_i * G, k_i from splitmix64(seed, i)
+// ------------------------------------------------------------------------------------------
+MSM_HD uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+template <class F>
+__global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed, uint32_t n, uint8_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k[4];
+    for (int j = 0; j < 4; ++j) k[j] = splitmix64(seed * 0x100000001B3ull + (uint64_t)i * 4 + j);
+    k[3] &= 0x3fffffffffffffffull;   // 254-bit multipliers
+    if ((k[0] | k[1] | k[2] | k[3]) == 0) k[0] = 1;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = XYZZ<F>::dbl(acc);
+        if ((k[bit >> 6] >> (bit & 63)) & 1ull) XYZZ<F>::madd(acc, gen.x, gen.y);
+    }
+    Affine<F> a = XYZZ<F>::to_affine(acc);
+    store16(out + (size_t)i * sizeof(Affine<F>), a);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace msm
+
+using namespace msm;
+
+struct msm_amd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string err;
+    uint32_t force_c = 0;
+    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
+    void* h_partials = nullptr;   // pinned
+    size_t h_partials_cap = 0;
+    float timings[8] = {};
+    uint32_t geometry[4] = {};
+};
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                     \
+            return MSM_AMD_EHIP;                                                                               \
+        }                                                                                                      \
+    } while (0)
+
+static int ensure(msm_amd_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return 0;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+template <class F>
+static void host_store_jacobian_normalised(const XYZZ<F>& r, uint8_t* out) {
+    Affine<F> a = XYZZ<F>::to_affine(r);
+    F one = F::one(), zero = F::zero();
+    if (r.is_inf()) {
+        memcpy(out, &zero, sizeof(F));
+        memcpy(out + sizeof(F), &one, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &zero, sizeof(F));
+    } else {
+        memcpy(out, &a.x, sizeof(F));
+        memcpy(out + sizeof(F), &a.y, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &one, sizeof(F));
+    }
+}
+// un-normalised Jacobian image of an XYZZ point: (X*ZZ*ZZZ^2.. ) -- choose Z = ZZZ*ZZ? we use the
+// identity x = X/ZZ = (X*ZZ)/ZZ^2... simplest exact map: Z = ZZ * ZZZ, X' = X * ZZ * ZZZ^2, Y' = Y * ZZ^3 * ZZZ^2.
+// (Z^2 = ZZ^2 ZZZ^2 => X'/Z^2 = X/ZZ ; Z^3 = ZZ^3 ZZZ^3 => Y'/Z^3 = Y/ZZZ.)
+template <class F>
+static void host_store_jacobian_raw(const XYZZ<F>& r, uint8_t* out) {
+    F one = F::one(), zero = F::zero();
+    if (r.is_inf()) {
+        memcpy(out, &zero, sizeof(F));
+        memcpy(out + sizeof(F), &one, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &zero, sizeof(F));
+        return;
+    }
+    F zzz2 = F::sqr(r.zzz);
+    F x = F::mul(F::mul(r.x, r.zz), zzz2);
+    F zz3 = F::mul(F::sqr(r.zz), r.zz);
+    F y = F::mul(F::mul(r.y, zz3), zzz2);
+    F z = F::mul(r.zz, r.zzz);
+    memcpy(out, &x, sizeof(F));
+    memcpy(out + sizeof(F), &y, sizeof(F));
+    memcpy(out + 2 * sizeof(F), &z, sizeof(F));
+}
+template <class F>
+static XYZZ<F> host_load_jacobian(const uint8_t* in) {
+    Jacobian<F> j;
+    memcpy(&j, in, sizeof(j));
+    return XYZZ<F>::from_jacobian(j);
+}
+
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
+    uint32_t c;
+    if (forced) {
+        c = forced;
+    } else {
+        uint32_t lg = 0;
+        while ((1ull << lg) < n) ++lg;
+        c = lg > 4 ? lg - 4 : 1;
+        if (c > 16) c = 16;
+    }
+    if (c > nbits) c = nbits;
+    if (c < 1) c = 1;
+    if (c > 22) c = 22;
+    return c;
+}
+
+struct RunArgs {
+    const void* bases;
+    const void* scalars;
+    uint32_t scalar_size, n, flags;
+    uint32_t bit_lo, nbits;   // scalar bit range
+    uint32_t shard, nshards;
+    bool raw_out;             // un-normalised Jacobian partial (multi-GPU shard)
+};
+
+template <class F>
+static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
+    using X = XYZZ<F>;
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);
+    for (float& t : ctx->timings) t = 0.f;
+    if (a.n == 0 || a.nbits == 0) {
+        X inf = X::inf();
+        host_store_jacobian_normalised(inf, out);
+        return 0;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool dev_ptrs = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
+    const size_t base_bytes = (size_t)a.n * (jac ? JSZ : ASZ);
+    const size_t scalar_bytes = (size_t)a.n * a.scalar_size;
+
+    const uint8_t* d_bases;
+    const uint8_t* d_scalars;
+    if (dev_ptrs) {
+        if (((uintptr_t)a.bases & 15) != 0) {
+            ctx->err = "device bases pointer must be 16-byte aligned";
+            return MSM_AMD_EINVAL;
+        }
+        d_bases = (const uint8_t*)a.bases;
+        d_scalars = (const uint8_t*)a.scalars;
+    } else {
+        if (int rc = ensure(ctx, ctx->d_bases, base_bytes)) return rc;
+        if (int rc = ensure(ctx, ctx->d_scalars, scalar_bytes + 8)) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_bases.p, a.bases, base_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
+        d_bases = (const uint8_t*)ctx->d_bases.p;
+        d_scalars = (const uint8_t*)ctx->d_scalars.p;
+    }
+
+    Geom g;
+    g.n = a.n;
+    g.scalar_size = a.scalar_size;
+    g.bit_lo = a.bit_lo;
+    g.nbits = a.nbits;
+    g.c = pick_window_bits(a.n, a.nbits, ctx->force_c);
+    g.W = a.nbits / g.c + 1;
+    g.half = 1u << (g.c - 1);
+    g.shard = a.shard;
+    g.nshards = a.nshards;
+    g.Wl = 0;
+    for (uint32_t w = 0; w < g.W; ++w)
+        if (w % g.nshards == g.shard) ++g.Wl;
+    ctx->geometry[0] = g.c;
+    ctx->geometry[1] = g.W;
+    ctx->geometry[2] = g.half;
+    ctx->geometry[3] = g.Wl;
+    if (g.Wl == 0) {
+        X inf = X::inf();
+        host_store_jacobian_normalised(inf, out);
+        return 0;
+    }
+    const uint32_t NB = g.Wl * g.half;
+    const bool fast = (a.scalar_size % 4 == 0) && (((uintptr_t)d_scalars & 3) == 0);
+
+    HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+    // ---- Jacobian bases -> affine
+    if (jac) {
+        if (int rc = ensure(ctx, ctx->d_affine, (size_t)a.n * ASZ)) return rc;
+        uint32_t lanes = (a.n + 7) / 8;
+        k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)ctx->d_affine.p);
+        d_bases = (const uint8_t*)ctx->d_affine.p;
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+
+    const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
+    if (int rc = ensure(ctx, ctx->d_count, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_offset, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_cursor, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_order, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_bins, ORDER_BINS * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_tiles, (size_t)ntiles * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_buckets, (size_t)NB * XSZ)) return rc;
+    uint32_t* count = (uint32_t*)ctx->d_count.p;
+    uint32_t* offset = (uint32_t*)ctx->d_offset.p;
+    uint32_t* cursor = (uint32_t*)ctx->d_cursor.p;
+    uint32_t* order = (uint32_t*)ctx->d_order.p;
+    uint32_t* bins = (uint32_t*)ctx->d_bins.p;
+    uint32_t* tiles = (uint32_t*)ctx->d_tiles.p;
+    uint32_t* sorted = (uint32_t*)ctx->d_sorted.p;
+
+    // ---- 1. digits + histogram
+    HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_BINS * 4, st));
+    const uint32_t nblk = (a.n + 255) / 256;
+    if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+    else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+    // ---- 2. scan + order
+    k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
+    k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
+    k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
+    const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
+    k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
+    k_order_scan<<<1, 1024, 0, st>>>(bins);
+    k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+    // ---- 3. scatter
+    if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+    else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    // ---- 4. accumulate
+    k_accumulate<F><<<(NB + 255) / 256, 256, 0, st>>>(d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
+    // ---- 5. reduce
+    uint32_t L = std::max(1u, g.half / 8192u);
+    uint32_t lanes_per_window = (g.half + L - 1) / L;
+    uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
+    // LDS budget: rblock * XSZ must fit in 64 KB (default limit); shrink for wide fields
+    while ((size_t)rblock * XSZ > 64 * 1024 && rblock > 64) rblock /= 2;
+    uint32_t wgs_per_window = (lanes_per_window + rblock - 1) / rblock;
+    uint32_t nparts = g.Wl * wgs_per_window;
+    if (int rc = ensure(ctx, ctx->d_partials, (size_t)nparts * XSZ)) return rc;
+    if (ctx->h_partials_cap < (size_t)nparts * XSZ) {
+        if (ctx->h_partials) HIPCHK(ctx, hipHostFree(ctx->h_partials));
+        ctx->h_partials = nullptr;
+        ctx->h_partials_cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_partials, (size_t)nparts * XSZ * 2, hipHostMallocDefault));
+        ctx->h_partials_cap = (size_t)nparts * XSZ * 2;
+    }
+    k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * XSZ, st>>>((const uint8_t*)ctx->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
+                                                                   (uint8_t*)ctx->d_partials.p);
+    HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipGetLastError());
+
+    // ---- 6. host combine: window sums, Horner over owned windows (top first), each weighted 2^(c*w)
+    auto t0 = std::chrono::steady_clock::now();
+    const X* parts = reinterpret_cast<const X*>(ctx->h_partials);
+    X total = X::inf();
+    int prev_w = -1;   // global index of the window most recently folded in
+    for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
+        int wglob = wl * (int)g.nshards + (int)g.shard;
+        if (prev_w >= 0)
+            for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = X::dbl(total);
+        X s = X::inf();
+        for (uint32_t k = 0; k < wgs_per_window; ++k) s = X::add(s, parts[(size_t)wl * wgs_per_window + k]);
+        total = X::add(total, s);
+        prev_w = wglob;
+    }
+    for (int k = 0; k < prev_w * (int)g.c; ++k) total = X::dbl(total);
+    if (a.raw_out) host_store_jacobian_raw(total, out);
+    else host_store_jacobian_normalised(total, out);
+    auto t1 = std::chrono::steady_clock::now();
+
+    float ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]); ctx->timings[0] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->timings[1] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->timings[2] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); ctx->timings[3] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]); ctx->timings[4] = ms;
+    (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->timings[5] = ms;
+    ctx->timings[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->timings[7] = ms;
+    return 0;
+}
+
+static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (!out || (a.n && (!a.bases || !a.scalars))) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    if (a.scalar_size < 1 || a.scalar_size > 64) {
+        ctx->err = "scalar_size must be in [1, 64]";
+        return MSM_AMD_EINVAL;
+    }
+    if (a.nshards == 0 || a.shard >= a.nshards) {
+        ctx->err = "bad shard";
+        return MSM_AMD_EINVAL;
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 1) return run_msm<Fp<Bls12381Fp>>(ctx, a, out);
+    if (curve == MSM_AMD_BLS12381 && group == 2) return run_msm<Fp2<Bls12381Fp>>(ctx, a, out);
+    if (curve == MSM_AMD_BN128 && group == 1) return run_msm<Fp<Bn254Fp>>(ctx, a, out);
+    if (curve == MSM_AMD_BN128 && group == 2) return run_msm<Fp2<Bn254Fp>>(ctx, a, out);
+    ctx->err = "unknown curve/group";
+    return MSM_AMD_EINVAL;
+}
+
+template <class F>
+static int gen_points_t(msm_amd_ctx* ctx, const Affine<F>& gen, uint64_t seed, uint32_t n, void* dev_out) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    k_gen_points<F><<<(n + 255) / 256, 256, 0, ctx->stream>>>(gen, seed, n, (uint8_t*)dev_out);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+template <class P>
+static Fp<P> fp_from(const uint32_t* limbs) {
+    Fp<P> r;
+    for (int i = 0; i < P::N; ++i) r.v[i] = limbs[i];
+    return r;
+}
+
+template <class F>
+static int combine_t(const uint8_t* partials, uint32_t count, uint8_t* out) {
+    XYZZ<F> total = XYZZ<F>::inf();
+    for (uint32_t i = 0; i < count; ++i) total = XYZZ<F>::add(total, host_load_jacobian<F>(partials + (size_t)i * sizeof(Jacobian<F>)));
+    host_store_jacobian_normalised(total, out);
+    return 0;
+}
+template <class F, bool TO>
+static int f_conv(const uint8_t* in, uint32_t count, uint8_t* out) {
+    for (uint32_t i = 0; i < count; ++i) {
+        F x;
+        memcpy(&x, in + (size_t)i * sizeof(F), sizeof(F));
+        F r = TO ? F::to_mont(x) : F::from_mont(x);
+        memcpy(out + (size_t)i * sizeof(F), &r, sizeof(F));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
+    if (!out_ctx) return MSM_AMD_EINVAL;
+    *out_ctx = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return MSM_AMD_EHIP;
+    msm_amd_ctx* ctx = new (std::nothrow) msm_amd_ctx();
+    if (!ctx) return MSM_AMD_ENOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return MSM_AMD_EHIP;
+    }
+    for (auto& e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return MSM_AMD_EHIP;
+        }
+    *out_ctx = ctx;
+    return MSM_AMD_OK;
+}
+
+void msm_amd_destroy(msm_amd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
+                      &ctx->d_tiles, &ctx->d_sorted, &ctx->d_buckets, &ctx->d_partials})
+        if (b->p) (void)hipFree(b->p);
+    if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* msm_amd_last_error(const msm_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
+    if (!ctx || c > 22) return MSM_AMD_EINVAL;
+    ctx->force_c = c;
+    return 0;
+}
+
+int msm_amd_multiexp(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
+                     uint32_t n, uint8_t* out) {
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
+    return dispatch(ctx, curve, group, a, out);
+}
+
+int msm_amd_multiexp_chunk(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                           uint32_t scalar_size, uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (chunk_size < 1 || chunk_size > 25) {   // build_multiexp.js:25-94 is exact for chunkSize <= 25
+        ctx->err = "chunk_size must be in [1, 25]";
+        return MSM_AMD_EINVAL;
+    }
+    uint32_t total = scalar_size * 8;
+    uint32_t nbits = start_bit >= total ? 0u : std::min(chunk_size, total - start_bit);
+    RunArgs a{bases, scalars, scalar_size, n, flags, start_bit, nbits, 0, 1, false};
+    return dispatch(ctx, curve, group, a, out);
+}
+
+int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                           uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards, uint8_t* out_partial) {
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, shard, nshards, true};
+    return dispatch(ctx, curve, group, a, out_partial);
+}
+
+#define BY_FIELD(curve, group, CALL)                                                         \
+    do {                                                                                     \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 1) { using F = Fp<Bls12381Fp>; CALL; }  \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 2) { using F = Fp2<Bls12381Fp>; CALL; } \
+        if ((curve) == MSM_AMD_BN128 && (group) == 1) { using F = Fp<Bn254Fp>; CALL; }        \
+        if ((curve) == MSM_AMD_BN128 && (group) == 2) { using F = Fp2<Bn254Fp>; CALL; }       \
+    } while (0)
+
+int msm_amd_combine(int curve, int group, const uint8_t* partials, uint32_t count, uint8_t* out) {
+    if (!partials || !out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, return combine_t<F>(partials, count, out));
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_normalize(int curve, int group, const uint8_t* jac_in, uint8_t* jac_out) {
+    if (!jac_in || !jac_out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        host_store_jacobian_normalised(host_load_jacobian<F>(jac_in), jac_out);
+        return 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_to_affine(int curve, int group, const uint8_t* jac_in, uint8_t* aff_out) {
+    if (!jac_in || !aff_out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        Affine<F> a = XYZZ<F>::to_affine(host_load_jacobian<F>(jac_in));
+        memcpy(aff_out, &a, sizeof(a));
+        return 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_eq(int curve, int group, const uint8_t* jac_a, const uint8_t* jac_b) {
+    if (!jac_a || !jac_b) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        XYZZ<F> d = XYZZ<F>::add(host_load_jacobian<F>(jac_a), XYZZ<F>::neg(host_load_jacobian<F>(jac_b)));
+        return d.is_inf() ? 1 : 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_f_to_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
+    if (!in || !out) return MSM_AMD_EINVAL;
+    if (curve == MSM_AMD_BLS12381) return f_conv<Fp<Bls12381Fp>, true>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<Fp<Bn254Fp>, true>(in, count, out);
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_f_from_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
+    if (!in || !out) return MSM_AMD_EINVAL;
+    if (curve == MSM_AMD_BLS12381) return f_conv<Fp<Bls12381Fp>, false>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<Fp<Bn254Fp>, false>(in, count, out);
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_dev_alloc(msm_amd_ctx* ctx, size_t bytes, void** dev_ptr) {
+    if (!ctx || !dev_ptr) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return 0;
+}
+int msm_amd_dev_free(msm_amd_ctx* ctx, void* dev_ptr) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(dev_ptr));
+    return 0;
+}
+int msm_amd_h2d(msm_amd_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int msm_amd_d2h(msm_amd_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int msm_amd_gen_points(msm_amd_ctx* ctx, int curve, int group, uint64_t seed, uint32_t n, void* dev_out) {
+    if (!ctx || !dev_out) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (curve == MSM_AMD_BLS12381 && group == 1) {
+        using P = Bls12381Fp;
+        Affine<Fp<P>> g{fp_from<P>(P::G1X), fp_from<P>(P::G1Y)};
+        return gen_points_t<Fp<P>>(ctx, g, seed, n, dev_out);
+    }
+    if (curve == MSM_AMD_BN128 && group == 1) {
+        using P = Bn254Fp;
+        Affine<Fp<P>> g{fp_from<P>(P::G1X), fp_from<P>(P::G1Y)};
+        return gen_points_t<Fp<P>>(ctx, g, seed, n, dev_out);
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 2) {
+        using P = Bls12381Fp;
+        Affine<Fp2<P>> g{{fp_from<P>(P::G2X0), fp_from<P>(P::G2X1)}, {fp_from<P>(P::G2Y0), fp_from<P>(P::G2Y1)}};
+        return gen_points_t<Fp2<P>>(ctx, g, seed, n, dev_out);
+    }
+    if (curve == MSM_AMD_BN128 && group == 2) {
+        using P = Bn254Fp;
+        Affine<Fp2<P>> g{{fp_from<P>(P::G2X0), fp_from<P>(P::G2X1)}, {fp_from<P>(P::G2Y0), fp_from<P>(P::G2Y1)}};
+        return gen_points_t<Fp2<P>>(ctx, g, seed, n, dev_out);
+    }
+    ctx->err = "unknown curve/group";
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_get_timings(const msm_amd_ctx* ctx, float* ms, int capacity) {
+    if (!ctx || !ms) return MSM_AMD_EINVAL;
+    int k = std::min(capacity, 8);
+    for (int i = 0; i < k; ++i) ms[i] = ctx->timings[i];
+    return k;
+}
+int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out4) {
+    if (!ctx || !out4) return MSM_AMD_EINVAL;
+    for (int i = 0; i < 4; ++i) out4[i] = ctx->geometry[i];
+    return 0;
+}
+
+#define MSM_AMD_DEF(curve, g, CID, GID)                                                                                                    \
+    int msm_##curve##_##g##_multiexp(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size, uint32_t n,     \
+                                     uint8_t* out) {                                                                                       \
+        return msm_amd_multiexp(ctx, CID, GID, MSM_AMD_BASES_JACOBIAN, bases, scalars, scalar_size, n, out);                               \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexpAffine(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,           \
+                                           uint32_t n, uint8_t* out) {                                                                     \
+        return msm_amd_multiexp(ctx, CID, GID, 0, bases, scalars, scalar_size, n, out);                                                    \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexp_chunk(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,           \
+                                           uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {                            \
+        return msm_amd_multiexp_chunk(ctx, CID, GID, MSM_AMD_BASES_JACOBIAN, bases, scalars, scalar_size, n, start_bit, chunk_size, out);  \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexpAffine_chunk(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,     \
+                                                 uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {                      \
+        return msm_amd_multiexp_chunk(ctx, CID, GID, 0, bases, scalars, scalar_size, n, start_bit, chunk_size, out);                       \
+    }
+MSM_AMD_DEF(bls12381, g1m, MSM_AMD_BLS12381, 1)
+MSM_AMD_DEF(bls12381, g2m, MSM_AMD_BLS12381, 2)
+MSM_AMD_DEF(bn128, g1m, MSM_AMD_BN128, 1)
+MSM_AMD_DEF(bn128, g2m, MSM_AMD_BN128, 2)
+
+}  // extern "C"

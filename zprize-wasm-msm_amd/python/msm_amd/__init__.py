@@ -1,0 +1,288 @@
+"""Host-side Python mirror of the reference's WASM export surface for the MSM path, backed by the
+HIP engine (libmsm_amd.so) through its C ABI (include/msm_amd.h).
+
+The reference exposes, per curve module (wasmcurves/build/bls12381.wasm, bn128.wasm):
+    g1m_multiexp, g1m_multiexpAffine, g1m_multiexp_chunk, g1m_multiexpAffine_chunk, g2m_* ...
+    (wasmcurves/src/build_multiexp.js:251-257,96-104; wired at build_curve_jacobian_a0.js:1426-1430)
+called as  pb.g1m_multiexpAffine(pBases, pScalars, scalarSize, n, pOut)  (wasmcurves/test/bn128.js:493).
+Here the same names take byte buffers instead of linear-memory offsets and return the result bytes:
+
+    eng = msm_amd.Engine()                       # one context on one GPU
+    bls = eng.curve("bls12381")
+    out = bls.g1m_multiexpAffine(bases, scalars, 32, n)      # 144 bytes, normalised Jacobian
+
+There is no CPU fallback: if the HIP library cannot be loaded or no GPU is present, construction
+raises.  PyTorch is optional plumbing: CUDA tensors are accepted as device-resident inputs.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmsm_amd.so"))
+
+CURVES = {"bls12381": 0, "bn128": 1}
+N8 = {"bls12381": 48, "bn128": 32}
+
+FLAG_JACOBIAN = 1
+FLAG_DEVICE = 2
+
+
+class MsmAmdError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libmsm_amd.so (raises MsmAmdError if it is missing: the product has no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("MSM_AMD_LIB", _LIB_PATH)
+    if not os.path.exists(path):
+        raise MsmAmdError(f"HIP engine library not found at {path}; build it with `python __graft_entry__.py` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    c = ctypes
+    vp, u32, u8p = c.c_void_p, c.c_uint32, c.c_void_p
+    L.msm_amd_create.argtypes = [c.c_int, c.POINTER(vp)]
+    L.msm_amd_destroy.argtypes = [vp]
+    L.msm_amd_destroy.restype = None
+    L.msm_amd_last_error.argtypes = [vp]
+    L.msm_amd_last_error.restype = c.c_char_p
+    L.msm_amd_set_window_bits.argtypes = [vp, u32]
+    L.msm_amd_multiexp.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
+    L.msm_amd_multiexp_chunk.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
+    L.msm_amd_multiexp_shard.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
+    L.msm_amd_combine.argtypes = [c.c_int, c.c_int, vp, u32, u8p]
+    L.msm_amd_normalize.argtypes = [c.c_int, c.c_int, vp, u8p]
+    L.msm_amd_to_affine.argtypes = [c.c_int, c.c_int, vp, u8p]
+    L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
+    L.msm_amd_f_to_montgomery.argtypes = [c.c_int, vp, u32, u8p]
+    L.msm_amd_f_from_montgomery.argtypes = [c.c_int, vp, u32, u8p]
+    L.msm_amd_dev_alloc.argtypes = [vp, c.c_size_t, c.POINTER(vp)]
+    L.msm_amd_dev_free.argtypes = [vp, vp]
+    L.msm_amd_h2d.argtypes = [vp, vp, vp, c.c_size_t]
+    L.msm_amd_d2h.argtypes = [vp, vp, vp, c.c_size_t]
+    L.msm_amd_gen_points.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u32, vp]
+    L.msm_amd_get_timings.argtypes = [vp, c.POINTER(c.c_float), c.c_int]
+    L.msm_amd_get_geometry.argtypes = [vp, c.POINTER(u32)]
+    _lib = L
+    return L
+
+
+class DeviceBuffer:
+    """GPU memory owned by an Engine (hipMalloc); `.ptr` is the raw device address."""
+
+    def __init__(self, eng, nbytes):
+        self.eng, self.nbytes = eng, nbytes
+        p = ctypes.c_void_p()
+        eng._chk(eng.L.msm_amd_dev_alloc(eng.ctx, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, data):
+        data = bytes(data)
+        assert len(data) <= self.nbytes
+        self.eng._chk(self.eng.L.msm_amd_h2d(self.eng.ctx, self.ptr, data, len(data)))
+        return self
+
+    def download(self, nbytes=None):
+        nbytes = self.nbytes if nbytes is None else nbytes
+        buf = ctypes.create_string_buffer(nbytes)
+        self.eng._chk(self.eng.L.msm_amd_d2h(self.eng.ctx, buf, self.ptr, nbytes))
+        return buf.raw
+
+    def free(self):
+        if self.ptr:
+            self.eng.L.msm_amd_dev_free(self.eng.ctx, self.ptr)
+            self.ptr = None
+
+
+def _as_ptr(x):
+    """(pointer, is_device, keepalive) for bytes-like, numpy, DeviceBuffer or torch tensors."""
+    if isinstance(x, DeviceBuffer):
+        return x.ptr, True, x
+    if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):   # torch.Tensor
+        if not x.is_contiguous():
+            raise MsmAmdError("tensor must be contiguous")
+        return x.data_ptr(), bool(x.is_cuda), x
+    if hasattr(x, "ctypes") and hasattr(x, "flags"):       # numpy
+        if not x.flags["C_CONTIGUOUS"]:
+            raise MsmAmdError("array must be C-contiguous")
+        return x.ctypes.data, False, x
+    b = bytes(x) if not isinstance(x, bytes) else x
+    return ctypes.cast(ctypes.c_char_p(b), ctypes.c_void_p).value, False, b
+
+
+class Engine:
+    """One engine context = one GPU + one stream + its scratch buffers (msm_amd_create)."""
+
+    def __init__(self, device=0, lib_path=None):
+        self.L = load_library(lib_path)
+        ctx = ctypes.c_void_p()
+        rc = self.L.msm_amd_create(int(device), ctypes.byref(ctx))
+        if rc != 0:
+            raise MsmAmdError(f"msm_amd_create(device={device}) failed with {rc}: no usable MI355X / HIP runtime")
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.msm_amd_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MsmAmdError(f"libmsm_amd error {rc}: {self.L.msm_amd_last_error(self.ctx).decode()}")
+
+    def curve(self, name):
+        return Curve(self, name)
+
+    def set_window_bits(self, c):
+        self._chk(self.L.msm_amd_set_window_bits(self.ctx, int(c)))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def timings(self):
+        arr = (ctypes.c_float * 8)()
+        k = self.L.msm_amd_get_timings(self.ctx, arr, 8)
+        names = ["gpu_total", "histogram", "scan_order", "scatter", "accumulate", "reduce", "host_combine", "to_affine"]
+        return {names[i]: float(arr[i]) for i in range(k)}
+
+    def geometry(self):
+        arr = (ctypes.c_uint32 * 4)()
+        self.L.msm_amd_get_geometry(self.ctx, arr)
+        return {"c": arr[0], "windows": arr[1], "buckets_per_window": arr[2], "windows_owned": arr[3]}
+
+
+class Curve:
+    """Export-named view of one curve (the reference builds one WASM module per curve)."""
+
+    def __init__(self, eng, name):
+        if name not in CURVES:
+            raise MsmAmdError(f"unknown curve {name!r} (bls12381 | bn128)")
+        self.eng, self.name, self.cid, self.n8 = eng, name, CURVES[name], N8[name]
+
+    # sizes, as the reference's constants n8q etc.
+    def field_bytes(self, group): return self.n8 * group
+    def affine_bytes(self, group): return 2 * self.n8 * group
+    def jacobian_bytes(self, group): return 3 * self.n8 * group
+
+    def _multiexp(self, group, flags, bases, scalars, scalar_size, n):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        if dev_b != dev_s:
+            raise MsmAmdError("bases and scalars must both be host or both be device buffers")
+        if dev_b:
+            flags |= FLAG_DEVICE
+        out = ctypes.create_string_buffer(self.jacobian_bytes(group))
+        self.eng._chk(self.eng.L.msm_amd_multiexp(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, out))
+        return out.raw
+
+    def _chunk(self, group, flags, bases, scalars, scalar_size, n, start_bit, chunk_size):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        if dev_b != dev_s:
+            raise MsmAmdError("bases and scalars must both be host or both be device buffers")
+        if dev_b:
+            flags |= FLAG_DEVICE
+        out = ctypes.create_string_buffer(self.jacobian_bytes(group))
+        self.eng._chk(self.eng.L.msm_amd_multiexp_chunk(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
+                                                        start_bit, chunk_size, out))
+        return out.raw
+
+    # --- the reference's export names -------------------------------------------------------
+    def g1m_multiexp(self, bases, scalars, scalar_size, n): return self._multiexp(1, FLAG_JACOBIAN, bases, scalars, scalar_size, n)
+    def g1m_multiexpAffine(self, bases, scalars, scalar_size, n): return self._multiexp(1, 0, bases, scalars, scalar_size, n)
+    def g2m_multiexp(self, bases, scalars, scalar_size, n): return self._multiexp(2, FLAG_JACOBIAN, bases, scalars, scalar_size, n)
+    def g2m_multiexpAffine(self, bases, scalars, scalar_size, n): return self._multiexp(2, 0, bases, scalars, scalar_size, n)
+
+    def g1m_multiexp_chunk(self, bases, scalars, scalar_size, n, start_bit, chunk_size):
+        return self._chunk(1, FLAG_JACOBIAN, bases, scalars, scalar_size, n, start_bit, chunk_size)
+
+    def g1m_multiexpAffine_chunk(self, bases, scalars, scalar_size, n, start_bit, chunk_size):
+        return self._chunk(1, 0, bases, scalars, scalar_size, n, start_bit, chunk_size)
+
+    def g2m_multiexp_chunk(self, bases, scalars, scalar_size, n, start_bit, chunk_size):
+        return self._chunk(2, FLAG_JACOBIAN, bases, scalars, scalar_size, n, start_bit, chunk_size)
+
+    def g2m_multiexpAffine_chunk(self, bases, scalars, scalar_size, n, start_bit, chunk_size):
+        return self._chunk(2, 0, bases, scalars, scalar_size, n, start_bit, chunk_size)
+
+    # the opt-path signature (wasmcurves/src/build_multiexp_opt.js:1987-1996): scalarSize fixed at 32
+    def g1m_multiexp_multiExp(self, points, scalars, n): return self.g1m_multiexpAffine(points, scalars, 32, n)
+
+    # --- multi-GPU building blocks --------------------------------------------------------------
+    def multiexp_shard(self, group, bases, scalars, scalar_size, n, shard, nshards, jacobian_bases=False):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        out = ctypes.create_string_buffer(self.jacobian_bytes(group))
+        self.eng._chk(self.eng.L.msm_amd_multiexp_shard(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
+                                                        shard, nshards, out))
+        return out.raw
+
+    def gen_points(self, group, seed, n):
+        buf = self.eng.alloc(max(16, n * self.affine_bytes(group)))
+        self.eng._chk(self.eng.L.msm_amd_gen_points(self.eng.ctx, self.cid, group, seed, n, buf.ptr))
+        return buf
+
+
+# --- host-only helpers (no GPU, no context): the comparison functions the reference's tests use ---
+def combine(curve, group, partials):
+    L = load_library()
+    jsz = 3 * N8[curve] * group
+    cnt = len(partials) // jsz
+    out = ctypes.create_string_buffer(jsz)
+    rc = L.msm_amd_combine(CURVES[curve], group, bytes(partials), cnt, out)
+    if rc:
+        raise MsmAmdError(f"msm_amd_combine failed: {rc}")
+    return out.raw
+
+
+def normalize(curve, group, jac):
+    L = load_library()
+    out = ctypes.create_string_buffer(3 * N8[curve] * group)
+    if L.msm_amd_normalize(CURVES[curve], group, bytes(jac), out):
+        raise MsmAmdError("msm_amd_normalize failed")
+    return out.raw
+
+
+def to_affine(curve, group, jac):
+    L = load_library()
+    out = ctypes.create_string_buffer(2 * N8[curve] * group)
+    if L.msm_amd_to_affine(CURVES[curve], group, bytes(jac), out):
+        raise MsmAmdError("msm_amd_to_affine failed")
+    return out.raw
+
+
+def eq(curve, group, a, b):
+    L = load_library()
+    rc = L.msm_amd_eq(CURVES[curve], group, bytes(a), bytes(b))
+    if rc < 0:
+        raise MsmAmdError("msm_amd_eq failed")
+    return rc == 1
+
+
+def f_to_montgomery(curve, data):
+    L = load_library()
+    out = ctypes.create_string_buffer(len(data))
+    if L.msm_amd_f_to_montgomery(CURVES[curve], bytes(data), len(data) // N8[curve], out):
+        raise MsmAmdError("msm_amd_f_to_montgomery failed")
+    return out.raw
+
+
+def f_from_montgomery(curve, data):
+    L = load_library()
+    out = ctypes.create_string_buffer(len(data))
+    if L.msm_amd_f_from_montgomery(CURVES[curve], bytes(data), len(data) // N8[curve], out):
+        raise MsmAmdError("msm_amd_f_from_montgomery failed")
+    return out.raw
