@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- BLS12-381 G1 MSM throughput (scalar-point pairs/s) at n = 2^20 on N MI355X.
+
+A "step" is one MSM over the same n = 2^20 synthetic (scalar, point) pairs, inputs resident in
+HBM before the timed region.  N = 1: one call of the engine.  N > 1 (one process per GPU,
+torch.distributed over RCCL): the Pippenger windows are sharded over the ranks, each rank returns
+one Jacobian partial, an all_gather over xGMI (144 B per rank) exchanges them and the host adds
+them -- strong scaling of the same MSM.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with a `roofline` object for the
+dominant kernel (bucket accumulation) and a `cpu_baseline` object (the C oracle = a port of the
+reference algorithm, single thread, same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "zprize-wasm-msm_amd", "python")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+R_BLS = 52435875175126190479447740508185965837690552500527637822603658699938581184513
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def uniform_scalars_mod_r(n, seed):
+    """n scalars uniform in [0, r), 32 bytes little-endian each (rejection sampling on 255 bits)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = np.empty((n, 4), dtype=np.uint64)
+    r_limbs = [(R_BLS >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+    todo = np.arange(n)
+    while todo.size:
+        cand = rng.integers(0, 1 << 64, size=(todo.size, 4), dtype=np.uint64)
+        cand[:, 3] &= np.uint64((1 << 63) - 1)
+        # lexicographic compare cand < r from the top limb
+        lt = np.zeros(todo.size, dtype=bool)
+        eq = np.ones(todo.size, dtype=bool)
+        for i in (3, 2, 1, 0):
+            lt |= eq & (cand[:, i] < np.uint64(r_limbs[i]))
+            eq &= cand[:, i] == np.uint64(r_limbs[i])
+        out[todo[lt]] = cand[lt]
+        todo = todo[~lt]
+    return out.view(np.uint8).reshape(n, 32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--logn", type=int, default=20, help="log2 of the number of pairs (BASELINE config: 20)")
+    ap.add_argument("--curve", default="bls12381")
+    ap.add_argument("--group", type=int, default=1)
+    ap.add_argument("--window-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = 1 << args.logn
+    eng = msm_amd.Engine(local_rank)          # fails loudly without the HIP library / a GPU
+    if args.window_bits:
+        eng.set_window_bits(args.window_bits)
+    C = eng.curve(args.curve)
+    g = args.group
+    jsz = C.jacobian_bytes(g)
+
+    # synthetic inputs, identical on every rank: P_i = k_i * G (GPU generated), scalars uniform in [0, r)
+    pts = C.gen_points(g, 0xC0FFEE02, n)
+    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02)
+    d_scalars = torch.from_numpy(sc_host).to(dev)
+    torch.cuda.synchronize()
+
+    gather_buf = [torch.empty(jsz, dtype=torch.uint8, device=dev) for _ in range(world)]
+
+    def step():
+        if world == 1:
+            return C._multiexp(g, 0, pts, d_scalars, 32, n)
+        part = C.multiexp_shard(g, pts, d_scalars, 32, n, rank, world)
+        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+        dist.all_gather(gather_buf, mine)                      # RCCL over xGMI: world x 144 B
+        allp = torch.stack(gather_buf).cpu().numpy().tobytes()
+        return msm_amd.combine(args.curve, g, allp)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    result = None
+    for _ in range(args.warmup):
+        result = step()
+    stage_acc = {}
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+        for k, v in eng.timings().items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    geom = eng.geometry()
+    stages = {k: v / args.steps for k, v in stage_acc.items()}
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = n * args.steps / elapsed
+        aff = C.affine_bytes(g)
+        # roofline of the dominant kernel (bucket accumulation): algorithmic bytes per launch =
+        # scattered entries x (affine point + 4-byte index)   [SURVEY.md 8(d): B_accum = W*(point+4)]
+        alg_bytes = geom["entries"] * (aff + 4)
+        acc_ms = stages.get("accumulate", 0.0)
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        # scatter stage (histogram + scan/order + scatter): B_scatter = 32 + 4*W per pair
+        sc_ms = stages.get("histogram", 0) + stages.get("scan_order", 0) + stages.get("scatter", 0)
+        sc_bytes = n * 32 + geom["entries"] * 4
+        out = {
+            "metric": "BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
+                      else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}",
+            "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)" if args.curve == "bls12381" else "u32 limbs (254-bit Montgomery integers)",
+            "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); inputs resident in HBM",
+            "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
+                       "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
+                       "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
+            "roofline": {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms},
+            "roofline_scatter": {"kernels": "k_histogram + scan/order + k_scatter (HBM-bound stage)", "bound": "hbm",
+                                 "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
+                                 "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms},
+            "stages_ms": stages,
+            "result_x_prefix": result[:8].hex(),
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, pts, sc_host, n, result)
+        print(json.dumps(out), flush=True)
+    pts.free()
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, pts, sc_host, n, gpu_result):
+    """The oracle (C port of the reference algorithm, build_multiexp.js schedule, single thread) timed on
+    the host cores of this box on a bounded sample of the same workload; also a parity check."""
+    from oracle import oracle as orc
+    orc.build()
+    O = orc.Oracle(args.curve, args.group)
+    asz = 2 * O.fsz
+    m = min(n, 1 << 20)
+    # bound the CPU work to ~10-30 s: the C port runs ~1e5 pairs/s on one core
+    if args.group == 2:
+        m = min(m, 1 << 18)
+    bases = pts.download(m * asz)
+    sc = sc_host[:m].tobytes()
+    t0 = time.perf_counter()
+    ref = O.multiexp_affine(bases, sc, 32, m)
+    dt = time.perf_counter() - t0
+    ok = None
+    if m == n:
+        ok = (O.normalize(ref) == gpu_result)
+    return {"value": m / dt, "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} pairs of the same workload, one call of the oracle's multiexpAffine "
+                      f"(reference schedule: c by clz(n), unsigned digits, Jacobian addMixed, recursive reduceTable); {dt:.1f} s",
+            "matches_gpu_result": ok}
+
+
+if __name__ == "__main__":
+    main()

@@ -122,8 +122,9 @@ int msm_amd_gen_points(msm_amd_ctx *ctx, int curve, int group, uint64_t seed, ui
  *        [5] bucket reduction, [6] host combine (wall), [7] bases conversion (Jacobian input only).
  * Returns the number of entries written. */
 int msm_amd_get_timings(const msm_amd_ctx *ctx, float *ms, int capacity);
-/* Window geometry of the last call: [0] c, [1] windows W, [2] buckets per window, [3] windows processed */
-int msm_amd_get_geometry(const msm_amd_ctx *ctx, uint32_t *out4);
+/* Window geometry of the last call: [0] c, [1] windows W, [2] buckets per window, [3] windows processed,
+ * [4],[5] low/high word of the number of (pair, window) entries scattered into buckets */
+int msm_amd_get_geometry(const msm_amd_ctx *ctx, uint32_t *out6);
 
 #ifdef __cplusplus
 }

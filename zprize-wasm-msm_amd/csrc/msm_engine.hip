@@ -422,7 +422,7 @@ struct msm_amd_ctx {
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     float timings[8] = {};
-    uint32_t geometry[4] = {};
+    uint32_t geometry[6] = {};
 };
 
 #define HIPCHK(ctx, call)                                                                                      \
@@ -564,6 +564,7 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     ctx->geometry[1] = g.W;
     ctx->geometry[2] = g.half;
     ctx->geometry[3] = g.Wl;
+    ctx->geometry[4] = ctx->geometry[5] = 0;
     if (g.Wl == 0) {
         X inf = X::inf();
         host_store_jacobian_normalised(inf, out);
@@ -631,20 +632,29 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     uint32_t wgs_per_window = (lanes_per_window + rblock - 1) / rblock;
     uint32_t nparts = g.Wl * wgs_per_window;
     if (int rc = ensure(ctx, ctx->d_partials, (size_t)nparts * XSZ)) return rc;
-    if (ctx->h_partials_cap < (size_t)nparts * XSZ) {
+    if (ctx->h_partials_cap < (size_t)nparts * XSZ + 16) {
         if (ctx->h_partials) HIPCHK(ctx, hipHostFree(ctx->h_partials));
         ctx->h_partials = nullptr;
         ctx->h_partials_cap = 0;
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_partials, (size_t)nparts * XSZ * 2, hipHostMallocDefault));
-        ctx->h_partials_cap = (size_t)nparts * XSZ * 2;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
+        ctx->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
     }
     k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * XSZ, st>>>((const uint8_t*)ctx->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
                                                                    (uint8_t*)ctx->d_partials.p);
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, st));
+    // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
+    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->h_partials) + (size_t)nparts * XSZ);
+    HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipGetLastError());
+    {
+        uint64_t entries = (uint64_t)h_tail[0] + h_tail[1];
+        ctx->geometry[4] = (uint32_t)entries;
+        ctx->geometry[5] = (uint32_t)(entries >> 32);
+    }
 
     // ---- 6. host combine: window sums, Horner over owned windows (top first), each weighted 2^(c*w)
     auto t0 = std::chrono::steady_clock::now();
@@ -915,9 +925,9 @@ int msm_amd_get_timings(const msm_amd_ctx* ctx, float* ms, int capacity) {
     for (int i = 0; i < k; ++i) ms[i] = ctx->timings[i];
     return k;
 }
-int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out4) {
-    if (!ctx || !out4) return MSM_AMD_EINVAL;
-    for (int i = 0; i < 4; ++i) out4[i] = ctx->geometry[i];
+int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out6) {
+    if (!ctx || !out6) return MSM_AMD_EINVAL;
+    for (int i = 0; i < 6; ++i) out6[i] = ctx->geometry[i];
     return 0;
 }
 

@@ -158,9 +158,10 @@ class Engine:
         return {names[i]: float(arr[i]) for i in range(k)}
 
     def geometry(self):
-        arr = (ctypes.c_uint32 * 4)()
+        arr = (ctypes.c_uint32 * 6)()
         self.L.msm_amd_get_geometry(self.ctx, arr)
-        return {"c": arr[0], "windows": arr[1], "buckets_per_window": arr[2], "windows_owned": arr[3]}
+        return {"c": arr[0], "windows": arr[1], "buckets_per_window": arr[2], "windows_owned": arr[3],
+                "entries": arr[4] | (arr[5] << 32)}
 
 
 class Curve:
