@@ -62,6 +62,7 @@ def main():
     import torch
     import torch.distributed as dist
     import msm_amd
+    from msm_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -87,16 +88,11 @@ def main():
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
-    gather_buf = [torch.empty(jsz, dtype=torch.uint8, device=dev) for _ in range(world)]
-
     def step():
         if world == 1:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
-        part = C.multiexp_shard(g, pts, d_scalars, 32, n, rank, world)
-        mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-        dist.all_gather(gather_buf, mine)                      # RCCL over xGMI: world x 144 B
-        allp = torch.stack(gather_buf).cpu().numpy().tobytes()
-        return msm_amd.combine(args.curve, g, allp)
+        # windows sharded over the ranks; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
+        return mdist.multiexp_sharded(C, g, pts, d_scalars, 32, n, device=dev)
 
     def sync():
         torch.cuda.synchronize()

@@ -207,3 +207,18 @@ def test_full_size_properties(eng, orc, curve, group, logn):
     assert O.normalize(acc) == Rs
     for b in (ds, dt, du, pts):
         b.free()
+
+
+@pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 2)])
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_window_shards_sum_to_full(eng, orc, curve, group, nshards):
+    """msm_amd_multiexp_shard: the partials of all shards add up to the full MSM (multi-GPU decomposition,
+    exercised here on one GPU)."""
+    import msm_amd
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    n = 1500
+    bases, scalars = gu.random_case(curve, group, f"gpu:shard:{curve}:{group}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, s, nshards) for s in range(nshards))
+    assert msm_amd.combine(curve, group, parts) == exp

@@ -1,0 +1,393 @@
+/*
+ * addon.c -- thin N-API binding of the C ABI in include/msm_amd.h (no logic of its own).
+ *
+ * Host stays Node.js, as with the reference: the reference's callers reach the MSM through
+ *   pb.g1m_multiexpAffine(pBases, pScalars, scalarSize, n, pOut)      (wasmcurves/test/bn128.js:493,
+ *                                                                      wasmcurves/benchmarks/multiexp.js:37)
+ * i.e. a synchronous call on byte buffers.  This addon exposes the same operation on Uint8Array /
+ * Buffer arguments, plus an async variant that returns a Promise (ffjavascript's surface is async).
+ * index.js in this directory wraps it in the reference's export names.
+ *
+ * Build (see __graft_entry__.build_node_addon):  gcc -shared -fPIC -I/usr/include/node addon.c -ldl
+ * The engine library is dlopen()ed from ../csrc/libmsm_amd.so (or $MSM_AMD_LIB).
+ */
+#define _GNU_SOURCE
+#define NAPI_VERSION 6
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "msm_amd.h"
+
+/* ---- the engine, resolved at load time ---------------------------------------------------- */
+static void *g_lib;
+static int (*p_create)(int, msm_amd_ctx **);
+static void (*p_destroy)(msm_amd_ctx *);
+static const char *(*p_last_error)(const msm_amd_ctx *);
+static int (*p_set_window_bits)(msm_amd_ctx *, uint32_t);
+static int (*p_multiexp)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint8_t *);
+static int (*p_multiexp_chunk)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t *);
+static int (*p_normalize)(int, int, const uint8_t *, uint8_t *);
+static int (*p_to_affine)(int, int, const uint8_t *, uint8_t *);
+static int (*p_eq)(int, int, const uint8_t *, const uint8_t *);
+static int (*p_combine)(int, int, const uint8_t *, uint32_t, uint8_t *);
+static int (*p_f_to_m)(int, const uint8_t *, uint32_t, uint8_t *);
+static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
+
+static const char *load_engine(void) {
+    if (g_lib) return NULL;
+    const char *path = getenv("MSM_AMD_LIB");
+    char buf[4096];
+    if (!path) {
+        Dl_info info;
+        if (!dladdr((void *)&load_engine, &info) || !info.dli_fname) return "cannot locate addon";
+        snprintf(buf, sizeof buf, "%s", info.dli_fname);
+        char *slash = strrchr(buf, '/');
+        if (!slash) return "cannot locate addon directory";
+        snprintf(slash, sizeof buf - (size_t)(slash - buf), "/../csrc/libmsm_amd.so");
+        path = buf;
+    }
+    g_lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!g_lib) return dlerror();
+#define SYM(var, name)                                  \
+    *(void **)(&var) = dlsym(g_lib, name);              \
+    if (!var) return "libmsm_amd.so lacks " name;
+    SYM(p_create, "msm_amd_create")
+    SYM(p_destroy, "msm_amd_destroy")
+    SYM(p_last_error, "msm_amd_last_error")
+    SYM(p_set_window_bits, "msm_amd_set_window_bits")
+    SYM(p_multiexp, "msm_amd_multiexp")
+    SYM(p_multiexp_chunk, "msm_amd_multiexp_chunk")
+    SYM(p_normalize, "msm_amd_normalize")
+    SYM(p_to_affine, "msm_amd_to_affine")
+    SYM(p_eq, "msm_amd_eq")
+    SYM(p_combine, "msm_amd_combine")
+    SYM(p_f_to_m, "msm_amd_f_to_montgomery")
+    SYM(p_f_from_m, "msm_amd_f_from_montgomery")
+#undef SYM
+    return NULL;
+}
+
+#define NAPI_OK(call)                                                    \
+    do {                                                                 \
+        if ((call) != napi_ok) {                                         \
+            napi_throw_error(env, NULL, "N-API call failed: " #call);    \
+            return NULL;                                                 \
+        }                                                                \
+    } while (0)
+
+static int n8_of(int curve) { return curve == MSM_AMD_BLS12381 ? 48 : 32; }
+
+static int get_bytes(napi_env env, napi_value v, const uint8_t **data, size_t *len) {
+    bool is;
+    if (napi_is_buffer(env, v, &is) == napi_ok && is) {
+        void *p;
+        if (napi_get_buffer_info(env, v, &p, len) != napi_ok) return -1;
+        *data = (const uint8_t *)p;
+        return 0;
+    }
+    if (napi_is_typedarray(env, v, &is) == napi_ok && is) {
+        napi_typedarray_type t;
+        void *p;
+        napi_value ab;
+        size_t off, count;
+        if (napi_get_typedarray_info(env, v, &t, &count, &p, &ab, &off) != napi_ok) return -1;
+        if (t != napi_uint8_array) return -1;
+        *data = (const uint8_t *)p;
+        *len = count;
+        return 0;
+    }
+    return -1;
+}
+static int get_u32(napi_env env, napi_value v, uint32_t *out) { return napi_get_value_uint32(env, v, out) == napi_ok ? 0 : -1; }
+static int get_i32(napi_env env, napi_value v, int *out) {
+    int32_t t;
+    if (napi_get_value_int32(env, v, &t) != napi_ok) return -1;
+    *out = t;
+    return 0;
+}
+
+static void ctx_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    if (data && p_destroy) p_destroy((msm_amd_ctx *)data);
+}
+
+/* create(device) -> external */
+static napi_value js_create(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int device = 0;
+    if (argc >= 1) get_i32(env, argv[0], &device);
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    msm_amd_ctx *ctx = NULL;
+    int rc = p_create(device, &ctx);
+    if (rc != 0) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "msm_amd_create(device=%d) failed with %d: no usable GPU / HIP runtime (there is no CPU fallback)", device, rc);
+        napi_throw_error(env, "MSM_AMD_EHIP", msg);
+        return NULL;
+    }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, ctx, ctx_finalize, NULL, &ext));
+    return ext;
+}
+
+static napi_value js_set_window_bits(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    uint32_t c;
+    if (argc < 2 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_u32(env, argv[1], &c)) {
+        napi_throw_type_error(env, NULL, "setWindowBits(ctx, c)");
+        return NULL;
+    }
+    if (p_set_window_bits((msm_amd_ctx *)ctx, c)) napi_throw_range_error(env, NULL, "window bits out of range");
+    return NULL;
+}
+
+/* shared argument block of multiexp / multiexpChunk */
+typedef struct {
+    msm_amd_ctx *ctx;
+    int curve, group;
+    uint32_t flags, scalar_size, n, start_bit, chunk_size;
+    int is_chunk;
+    const uint8_t *bases, *scalars;
+    uint8_t out[288];
+    int rc;
+    char err[256];
+    /* async only */
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref ref_bases, ref_scalars;
+} call_t;
+
+static int parse_call(napi_env env, napi_callback_info info, call_t *c, int is_chunk) {
+    size_t argc = 10;
+    napi_value argv[10];
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return -1;
+    size_t need = is_chunk ? 10 : 8;
+    void *ctx;
+    size_t lb, ls;
+    if (argc < need || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &c->curve) ||
+        get_i32(env, argv[2], &c->group) || get_u32(env, argv[3], &c->flags) || get_bytes(env, argv[4], &c->bases, &lb) ||
+        get_bytes(env, argv[5], &c->scalars, &ls) || get_u32(env, argv[6], &c->scalar_size) || get_u32(env, argv[7], &c->n)) {
+        napi_throw_type_error(env, NULL, "expected (ctx, curve, group, flags, bases:Uint8Array, scalars:Uint8Array, scalarSize, n[, startBit, chunkSize])");
+        return -1;
+    }
+    c->ctx = (msm_amd_ctx *)ctx;
+    c->is_chunk = is_chunk;
+    if (is_chunk && (get_u32(env, argv[8], &c->start_bit) || get_u32(env, argv[9], &c->chunk_size))) {
+        napi_throw_type_error(env, NULL, "startBit and chunkSize must be unsigned integers");
+        return -1;
+    }
+    if (c->curve != MSM_AMD_BLS12381 && c->curve != MSM_AMD_BN128) {
+        napi_throw_range_error(env, NULL, "unknown curve");
+        return -1;
+    }
+    if (c->group != 1 && c->group != 2) {
+        napi_throw_range_error(env, NULL, "group must be 1 or 2");
+        return -1;
+    }
+    c->flags &= MSM_AMD_BASES_JACOBIAN; /* device pointers cannot come from JS */
+    size_t stride = (size_t)((c->flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * n8_of(c->curve) * c->group;
+    if (lb < (size_t)c->n * stride || ls < (size_t)c->n * c->scalar_size) {
+        napi_throw_range_error(env, NULL, "bases/scalars buffer shorter than n elements (the reference would trap on out-of-bounds memory)");
+        return -1;
+    }
+    return 0;
+}
+static void run_call(call_t *c) {
+    if (c->is_chunk)
+        c->rc = p_multiexp_chunk(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->start_bit, c->chunk_size, c->out);
+    else
+        c->rc = p_multiexp(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->out);
+    if (c->rc) snprintf(c->err, sizeof c->err, "libmsm_amd error %d: %s", c->rc, p_last_error(c->ctx));
+}
+static napi_value make_result(napi_env env, const call_t *c) {
+    size_t jsz = (size_t)3 * n8_of(c->curve) * c->group;
+    napi_value ab, arr;
+    void *data;
+    if (napi_create_arraybuffer(env, jsz, &data, &ab) != napi_ok) return NULL;
+    memcpy(data, c->out, jsz);
+    if (napi_create_typedarray(env, napi_uint8_array, jsz, ab, 0, &arr) != napi_ok) return NULL;
+    return arr;
+}
+
+static napi_value js_multiexp_common(napi_env env, napi_callback_info info, int is_chunk) {
+    call_t c;
+    memset(&c, 0, sizeof c);
+    if (parse_call(env, info, &c, is_chunk)) return NULL;
+    run_call(&c);
+    if (c.rc) {
+        napi_throw_error(env, "MSM_AMD_ERROR", c.err);
+        return NULL;
+    }
+    return make_result(env, &c);
+}
+static napi_value js_multiexp(napi_env env, napi_callback_info info) { return js_multiexp_common(env, info, 0); }
+static napi_value js_multiexp_chunk(napi_env env, napi_callback_info info) { return js_multiexp_common(env, info, 1); }
+
+/* async: the GPU call runs on a libuv worker; input buffers are pinned by references meanwhile */
+static void async_exec(napi_env env, void *data) {
+    (void)env;
+    run_call((call_t *)data);
+}
+static void async_done(napi_env env, napi_status status, void *data) {
+    call_t *c = (call_t *)data;
+    if (status != napi_ok || c->rc) {
+        napi_value msg, err;
+        napi_create_string_utf8(env, c->rc ? c->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, c->deferred, err);
+    } else {
+        napi_value res = make_result(env, c);
+        napi_resolve_deferred(env, c->deferred, res);
+    }
+    napi_delete_reference(env, c->ref_bases);
+    napi_delete_reference(env, c->ref_scalars);
+    napi_delete_async_work(env, c->work);
+    free(c);
+}
+static napi_value js_multiexp_async_common(napi_env env, napi_callback_info info, int is_chunk) {
+    call_t *c = (call_t *)calloc(1, sizeof *c);
+    if (!c) {
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    if (parse_call(env, info, c, is_chunk)) {
+        free(c);
+        return NULL;
+    }
+    size_t argc = 10;
+    napi_value argv[10], promise, name;
+    napi_get_cb_info(env, info, &argc, argv, NULL, NULL);
+    napi_create_reference(env, argv[4], 1, &c->ref_bases);
+    napi_create_reference(env, argv[5], 1, &c->ref_scalars);
+    napi_create_promise(env, &c->deferred, &promise);
+    napi_create_string_utf8(env, "msm_amd_multiexp", NAPI_AUTO_LENGTH, &name);
+    napi_create_async_work(env, NULL, name, async_exec, async_done, c, &c->work);
+    napi_queue_async_work(env, c->work);
+    return promise;
+}
+static napi_value js_multiexp_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 0); }
+static napi_value js_multiexp_chunk_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 1); }
+
+/* ---- host-only helpers: normalize / toAffine / eq / combine / Montgomery conversion -------- */
+static napi_value bytes_out(napi_env env, const uint8_t *src, size_t len) {
+    napi_value ab, arr;
+    void *data;
+    if (napi_create_arraybuffer(env, len, &data, &ab) != napi_ok) return NULL;
+    memcpy(data, src, len);
+    if (napi_create_typedarray(env, napi_uint8_array, len, ab, 0, &arr) != napi_ok) return NULL;
+    return arr;
+}
+static napi_value js_point_op(napi_env env, napi_callback_info info, int which) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int curve, group;
+    const uint8_t *a, *b = NULL;
+    size_t la, lb = 0;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    if (argc < 3 || get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_bytes(env, argv[2], &a, &la) ||
+        (which == 2 && (argc < 4 || get_bytes(env, argv[3], &b, &lb)))) {
+        napi_throw_type_error(env, NULL, "expected (curve, group, Uint8Array[, Uint8Array])");
+        return NULL;
+    }
+    if ((curve != 0 && curve != 1) || (group != 1 && group != 2)) {
+        napi_throw_range_error(env, NULL, "bad curve/group");
+        return NULL;
+    }
+    size_t fsz = (size_t)n8_of(curve) * group, jsz = 3 * fsz;
+    uint8_t out[288];
+    if (which == 3) { /* combine: any number of Jacobian points */
+        if (la % jsz) {
+            napi_throw_range_error(env, NULL, "partials must be a whole number of Jacobian points");
+            return NULL;
+        }
+        if (p_combine(curve, group, a, (uint32_t)(la / jsz), out)) {
+            napi_throw_error(env, NULL, "msm_amd_combine failed");
+            return NULL;
+        }
+        return bytes_out(env, out, jsz);
+    }
+    if (la < jsz || (which == 2 && lb < jsz)) {
+        napi_throw_range_error(env, NULL, "Jacobian point buffer too short");
+        return NULL;
+    }
+    if (which == 0) {
+        p_normalize(curve, group, a, out);
+        return bytes_out(env, out, jsz);
+    }
+    if (which == 1) {
+        p_to_affine(curve, group, a, out);
+        return bytes_out(env, out, 2 * fsz);
+    }
+    napi_value res;
+    napi_get_boolean(env, p_eq(curve, group, a, b) == 1, &res);
+    return res;
+}
+static napi_value js_normalize(napi_env env, napi_callback_info info) { return js_point_op(env, info, 0); }
+static napi_value js_to_affine(napi_env env, napi_callback_info info) { return js_point_op(env, info, 1); }
+static napi_value js_eq(napi_env env, napi_callback_info info) { return js_point_op(env, info, 2); }
+static napi_value js_combine(napi_env env, napi_callback_info info) { return js_point_op(env, info, 3); }
+
+static napi_value js_mont(napi_env env, napi_callback_info info, int to) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int curve;
+    const uint8_t *a;
+    size_t la;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    if (argc < 2 || get_i32(env, argv[0], &curve) || get_bytes(env, argv[1], &a, &la) || (curve != 0 && curve != 1) || la % (size_t)n8_of(curve)) {
+        napi_throw_type_error(env, NULL, "expected (curve, Uint8Array of whole field elements)");
+        return NULL;
+    }
+    uint8_t *out = (uint8_t *)malloc(la ? la : 1);
+    if (!out) return NULL;
+    (to ? p_f_to_m : p_f_from_m)(curve, a, (uint32_t)(la / (size_t)n8_of(curve)), out);
+    napi_value r = bytes_out(env, out, la);
+    free(out);
+    return r;
+}
+static napi_value js_to_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 1); }
+static napi_value js_from_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 0); }
+
+static napi_value init(napi_env env, napi_value exports) {
+    napi_property_descriptor props[] = {
+        {"create", NULL, js_create, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"setWindowBits", NULL, js_set_window_bits, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexp", NULL, js_multiexp, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpChunk", NULL, js_multiexp_chunk, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpAsync", NULL, js_multiexp_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpChunkAsync", NULL, js_multiexp_chunk_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"normalize", NULL, js_normalize, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"toAffine", NULL, js_to_affine, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"eq", NULL, js_eq, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+    };
+    napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, init)

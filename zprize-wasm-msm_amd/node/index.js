@@ -1,0 +1,105 @@
+/*
+ * index.js -- Node.js host side of the MI355X MSM engine, shaped like the reference.
+ *
+ * Two surfaces:
+ *
+ * 1. instantiate(curveName, {memory})  ->  an object with the reference's WASM export names operating
+ *    on the caller's linear memory, so code written against the wasmcurves module keeps working:
+ *        const m = msm.instantiate("bls12381", { memory });
+ *        m.g1m_multiexpAffine(pBases, pScalars, scalarSize, n, pr);        // build_multiexp.js:251-257
+ *        m.g1m_multiexpAffine_chunk(pBases, pScalars, scalarSize, n, startBit, chunkSize, pr);   // :96-104
+ *    (also g1m_multiexp, g1m_multiexp_chunk, g2m_*; the opt-path alias g1m_multiexp_multiExp(p,s,n,pr)
+ *    of build_multiexp_opt.js:1987-1996).  Results are written through `pr` as a NORMALISED Jacobian point.
+ *
+ * 2. curve(curveName).G1 / .G2 with multiExp(buffBases, buffScalars) / multiExpAffine(...) returning a
+ *    Promise<Uint8Array> -- the call shape ffjavascript@0.2.56 gives its users (SURVEY.md section 8b; that
+ *    package is not part of the reference tree, so this surface is modelled, not pinned).
+ *
+ * No fallback: if the addon or libmsm_amd.so or a GPU is missing, loading / instantiate throws.
+ */
+"use strict";
+const path = require("path");
+
+const native = require(path.join(__dirname, "msm_amd_napi.node"));
+
+const CURVES = { bls12381: { id: 0, n8: 48 }, bn128: { id: 1, n8: 32 } };
+const FLAG_JACOBIAN = 1;
+
+let sharedCtx = null;
+function context(device) {
+    if (device === undefined) {
+        if (!sharedCtx) sharedCtx = native.create(0);
+        return sharedCtx;
+    }
+    return native.create(device);
+}
+
+function lookup(curveName) {
+    const c = CURVES[curveName];
+    if (!c) throw new RangeError(`unknown curve ${curveName} (bls12381 | bn128)`);
+    return c;
+}
+
+/** WASM-export-shaped view over a caller-owned WebAssembly.Memory (or any {buffer}) */
+function instantiate(curveName, imports, opts) {
+    const C = lookup(curveName);
+    const memory = imports && (imports.memory || (imports.env && imports.env.memory));
+    if (!memory) throw new TypeError("instantiate(curve, {memory}) needs the linear memory the offsets refer to");
+    const ctx = context(opts && opts.device);
+    const u8 = () => new Uint8Array(memory.buffer);
+    const ex = { memory };
+    for (const g of [1, 2]) {
+        const pf = `g${g}m`;
+        const fsz = C.n8 * g;
+        const mk = (flags, chunk) => function (pBases, pScalars, scalarSize, n, a, b, c) {
+            const stride = (flags & FLAG_JACOBIAN ? 3 : 2) * fsz;
+            const mem = u8();
+            const bases = mem.subarray(pBases, pBases + n * stride);
+            const scalars = mem.subarray(pScalars, pScalars + n * scalarSize);
+            let out, pr;
+            if (chunk) { out = native.multiexpChunk(ctx, C.id, g, flags, bases, scalars, scalarSize, n, a, b); pr = c; }
+            else { out = native.multiexp(ctx, C.id, g, flags, bases, scalars, scalarSize, n); pr = a; }
+            u8().set(out, pr);
+        };
+        ex[`${pf}_multiexp`] = mk(FLAG_JACOBIAN, false);
+        ex[`${pf}_multiexpAffine`] = mk(0, false);
+        ex[`${pf}_multiexp_chunk`] = mk(FLAG_JACOBIAN, true);
+        ex[`${pf}_multiexpAffine_chunk`] = mk(0, true);
+        // comparison helpers the reference's tests use around the MSM
+        ex[`${pf}_normalize`] = (p, pr) => u8().set(native.normalize(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);
+        ex[`${pf}_toAffine`] = (p, pr) => u8().set(native.toAffine(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);
+        ex[`${pf}_eq`] = (p1, p2) => (native.eq(C.id, g, u8().subarray(p1, p1 + 3 * fsz), u8().subarray(p2, p2 + 3 * fsz)) ? 1 : 0);
+    }
+    ex.g1m_multiexp_multiExp = (pPoints, pScalars, n, pr) => ex.g1m_multiexpAffine(pPoints, pScalars, 32, n, pr);
+    ex.f1m_toMontgomery = (p, pr) => u8().set(native.toMontgomery(C.id, u8().subarray(p, p + C.n8)), pr);
+    ex.f1m_fromMontgomery = (p, pr) => u8().set(native.fromMontgomery(C.id, u8().subarray(p, p + C.n8)), pr);
+    return ex;
+}
+
+/** ffjavascript-shaped async surface */
+function curve(curveName, opts) {
+    const C = lookup(curveName);
+    const ctx = context(opts && opts.device);
+    const group = (g) => {
+        const fsz = C.n8 * g;
+        const run = (flags, stride) => async function (buffBases, buffScalars) {
+            const n = Math.floor(buffBases.byteLength / stride);
+            if (n * stride !== buffBases.byteLength) throw new RangeError("bases length is not a whole number of points");
+            if (n === 0) return native.combine(C.id, g, new Uint8Array(0));
+            const scalarSize = Math.floor(buffScalars.byteLength / n);
+            if (scalarSize * n !== buffScalars.byteLength) throw new RangeError("scalars length is not a multiple of the number of points");
+            return native.multiexpAsync(ctx, C.id, g, flags, buffBases, buffScalars, scalarSize, n);
+        };
+        return {
+            F: { n8: fsz },
+            multiExp: run(FLAG_JACOBIAN, 3 * fsz),
+            multiExpAffine: run(0, 2 * fsz),
+            normalize: (p) => native.normalize(C.id, g, p),
+            toAffine: (p) => native.toAffine(C.id, g, p),
+            eq: (a, b) => native.eq(C.id, g, a, b),
+        };
+    };
+    return { name: curveName, n8q: C.n8, n8r: 32, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c) };
+}
+
+module.exports = { instantiate, curve, native, CURVES };

@@ -1,0 +1,98 @@
+#!/usr/bin/env node
+/*
+ * test_golden.js -- drives the N-API addon with the committed golden vectors (tests/golden/),
+ * through both JS surfaces of index.js.  Needs a GPU:  node test_golden.js [--host-only]
+ * Exit code 0 = all equal.  Invoked by tests/test_node_addon.py.
+ */
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const crypto = require("crypto");
+const msm = require("./index.js");
+
+const GOLD = path.join(__dirname, "..", "..", "tests", "golden");
+const R = {
+    bls12381: 52435875175126190479447740508185965837690552500527637822603658699938581184513n,
+    bn128: 21888242871839275222246405745257275088548364400416034343698204186575808495617n,
+};
+function stream(label, nbytes) {
+    const out = Buffer.alloc(nbytes);
+    for (let off = 0, k = 0; off < nbytes; off += 32, k++) crypto.createHash("sha256").update(label + ":" + k).digest().copy(out, off, 0, Math.min(32, nbytes - off));
+    return out;
+}
+const leToBig = (b) => { let v = 0n; for (let i = b.length - 1; i >= 0; i--) v = (v << 8n) | BigInt(b[i]); return v; };
+const bigToLe = (v, n) => { const b = Buffer.alloc(n); for (let i = 0; i < n; i++) { b[i] = Number(v & 0xffn); v >>= 8n; } return b; };
+
+function inputs(curve, G, pool, rec, asz) {
+    if (rec.bases !== undefined) return [Buffer.from(rec.bases, "hex"), Buffer.from(rec.scalars, "hex")];
+    const n = rec.n, rawp = stream(rec.label + ":p", 4 * n), raws = stream(rec.label + ":s", 32 * n);
+    const bases = Buffer.alloc(n * asz), scalars = Buffer.alloc(n * rec.scalar_size);
+    for (let i = 0; i < n; i++) {
+        const idx = rawp.readUInt32LE(4 * i) % G.pool_count;
+        pool.copy(bases, i * asz, idx * asz, (idx + 1) * asz);
+        bigToLe(leToBig(raws.slice(32 * i, 32 * i + 32)) % R[curve], 32).copy(scalars, i * rec.scalar_size, 0, Math.min(32, rec.scalar_size));
+    }
+    return [bases, scalars];
+}
+// the reference has two byte images of the identity after normalize: (0,R,0) and (0,0,R); the engine writes (0,R,0)
+function canon(hexNorm, fsz, zeroHex) {
+    const b = Buffer.from(hexNorm, "hex");
+    const xy0 = b.slice(0, 2 * fsz).every((x) => x === 0), z0 = b.slice(2 * fsz).every((x) => x === 0);
+    return (xy0 || z0) ? zeroHex : hexNorm;
+}
+
+async function main() {
+    const hostOnly = process.argv.includes("--host-only");
+    let checked = 0;
+    for (const curve of ["bls12381", "bn128"]) {
+        const gold = JSON.parse(fs.readFileSync(path.join(GOLD, `golden_${curve}.json`)));
+        const n8 = gold.n8;
+        for (const g of [1, 2]) {
+            const G = gold.groups["g" + g];
+            const fsz = n8 * g, asz = 2 * fsz, jsz = 3 * fsz;
+            const cid = msm.CURVES[curve].id;
+            const zeroHex = Buffer.from(msm.native.combine(cid, g, new Uint8Array(0))).toString("hex");
+            // host-only helpers against the golden group-op outputs
+            for (const rec of G.groupops) {
+                const got = Buffer.from(msm.native.normalize(cid, g, Buffer.from(rec.out_raw, "hex"))).toString("hex");
+                if (got !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`normalize mismatch ${curve} g${g} ${rec.op}`);
+                checked++;
+            }
+            if (hostOnly) continue;
+            const pool = fs.readFileSync(path.join(GOLD, G.pool_file));
+            // surface 1: WASM-export-shaped, caller-owned linear memory
+            const memory = new WebAssembly.Memory({ initial: 64 });
+            const m = msm.instantiate(curve, { memory });
+            const C = msm.curve(curve);
+            const Gx = g === 1 ? C.G1 : C.G2;
+            for (const rec of G.msm) {
+                const [bases, scalars] = inputs(curve, G, pool, rec, asz);
+                const affine = rec.fn === "multiexpAffine";
+                const pB = 1024, pS = pB + bases.length + 64, pR = pS + scalars.length + 64;
+                const mem = new Uint8Array(memory.buffer);
+                mem.set(bases, pB); mem.set(scalars, pS);
+                m[`g${g}m_${rec.fn}`](pB, pS, rec.scalar_size, rec.n, pR);
+                const got = Buffer.from(new Uint8Array(memory.buffer).slice(pR, pR + jsz)).toString("hex");
+                if (got !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: export-shaped result differs`);
+                for (const ch of rec.chunks || []) {
+                    m[`g${g}m_${rec.fn}_chunk`](pB, pS, rec.scalar_size, rec.n, ch.start_bit, ch.chunk_size, pR);
+                    const gc = Buffer.from(new Uint8Array(memory.buffer).slice(pR, pR + jsz)).toString("hex");
+                    if (gc !== canon(ch.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id} chunk ${ch.start_bit}/${ch.chunk_size} differs`);
+                    checked++;
+                }
+                // surface 2: async, buffers in / Uint8Array out
+                if (rec.n > 0 && rec.scalar_size * rec.n === scalars.length) {
+                    const out = await (affine ? Gx.multiExpAffine(bases, scalars) : Gx.multiExp(bases, scalars));
+                    if (Buffer.from(out).toString("hex") !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: async result differs`);
+                }
+                checked++;
+            }
+        }
+    }
+    // argument errors are thrown, not swallowed
+    let threw = false;
+    try { msm.native.normalize(0, 3, new Uint8Array(144)); } catch (e) { threw = true; }
+    if (!threw) throw new Error("bad group accepted");
+    console.log(`node addon: ${checked} checks passed${hostOnly ? " (host-only)" : ""}`);
+}
+main().catch((e) => { console.error(e.stack || e); process.exit(1); });
