@@ -254,41 +254,44 @@ struct Fp {
 
 // Fp2 = Fp[u]/(u^2 + 1): both reference curves pass mulNonResidueFn = "f1m_neg"
 // (bls12381/build_bls12381.js:48, bn128/build_bn128.js:43).
-template <class P>
-struct Fp2 {
-    using B = Fp<P>;
-    using Params = P;
+template <class B_>
+struct Fp2T {
+    using B = B_;
+    using Params = typename B::Params;
     static constexpr int BYTES = 2 * B::BYTES;
     B c0, c1;
 
-    MSM_HD static Fp2 zero() { return {B::zero(), B::zero()}; }
-    MSM_HD static Fp2 one() { return {B::one(), B::zero()}; }
+    MSM_HD static Fp2T zero() { return {B::zero(), B::zero()}; }
+    MSM_HD static Fp2T one() { return {B::one(), B::zero()}; }
     MSM_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
     MSM_HD bool is_one() const { return c0.is_one() && c1.is_zero(); }   // build_f2m.js:432-449
-    MSM_HD static bool eq(const Fp2& a, const Fp2& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
-    MSM_HD static Fp2 add(const Fp2& a, const Fp2& b) { return {B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
-    MSM_HD static Fp2 dbl(const Fp2& a) { return add(a, a); }
-    MSM_HD static Fp2 sub(const Fp2& a, const Fp2& b) { return {B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
-    MSM_HD static Fp2 neg(const Fp2& a) { return {B::neg(a.c0), B::neg(a.c1)}; }
-    MSM_HD static Fp2 cneg(const Fp2& a, bool f) { return {B::cneg(a.c0, f), B::cneg(a.c1, f)}; }
+    MSM_HD static bool eq(const Fp2T& a, const Fp2T& b) { return B::eq(a.c0, b.c0) && B::eq(a.c1, b.c1); }
+    MSM_HD static Fp2T add(const Fp2T& a, const Fp2T& b) { return {B::add(a.c0, b.c0), B::add(a.c1, b.c1)}; }
+    MSM_HD static Fp2T dbl(const Fp2T& a) { return add(a, a); }
+    MSM_HD static Fp2T sub(const Fp2T& a, const Fp2T& b) { return {B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
+    MSM_HD static Fp2T neg(const Fp2T& a) { return {B::neg(a.c0), B::neg(a.c1)}; }
+    MSM_HD static Fp2T cneg(const Fp2T& a, bool f) { return {B::cneg(a.c0, f), B::cneg(a.c1, f)}; }
     // build_f2m.js:152-188 (Karatsuba, 3 base multiplications)
-    MSM_HD static Fp2 mul(const Fp2& a, const Fp2& b) {
+    MSM_HD static Fp2T mul(const Fp2T& a, const Fp2T& b) {
         B A = B::mul(a.c0, b.c0);
         B Bb = B::mul(a.c1, b.c1);
         B C = B::mul(B::add(a.c0, a.c1), B::add(b.c0, b.c1));
         return {B::sub(A, Bb), B::sub(C, B::add(A, Bb))};
     }
     // build_f2m.js:211-252: (c0+c1)(c0-c1), 2 c0 c1
-    MSM_HD static Fp2 sqr(const Fp2& a) {
+    MSM_HD static Fp2T sqr(const Fp2T& a) {
         B ab = B::mul(a.c0, a.c1);
         B r0 = B::mul(B::add(a.c0, a.c1), B::sub(a.c0, a.c1));
         return {r0, B::add(ab, ab)};
     }
     // build_f2m.js:378-408
-    MSM_HD static Fp2 inv(const Fp2& a) {
+    MSM_HD static Fp2T inv(const Fp2T& a) {
         B t = B::inv(B::add(B::sqr(a.c0), B::sqr(a.c1)));
         return {B::mul(a.c0, t), B::neg(B::mul(a.c1, t))};
     }
 };
+
+template <class P>
+using Fp2 = Fp2T<Fp<P>>;
 
 }  // namespace msm

@@ -29,6 +29,7 @@
 
 #include "../../include/msm_amd.h"
 #include "curve.hpp"
+#include "field_host.hpp"
 
 namespace msm {
 
@@ -132,6 +133,173 @@ __global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ sca
         uint32_t pos = atomicAdd(&cursor[wl * g.half + b], 1u);
         sorted[pos] = i | (negd ? 0x80000000u : 0u);
     });
+}
+
+
+// ------------------------------------------------------------------------------------------
+// stage 1-3, LDS path (default): digits -> two-pass radix partition by bucket.
+//   k_digits          one lane per scalar, all windows: 16-bit signed-digit codes, window-major
+//                     (code = sign<<15 | (magnitude-1); 0xFFFF = zero digit)
+//   k_coarse_hist     per (tile, window): LDS histogram over the top bits of the bucket index
+//   (scan)            exclusive scan of the (window, coarse bin, tile) count matrix
+//   k_coarse_scatter  per (tile, window): local counting sort in LDS, then each (tile, bin) run is
+//                     written with consecutive lanes -> coalesced 8-byte entries {fine key, index}
+//   k_fine_sort       one workgroup per (window, coarse bin): histogram of the low bucket bits,
+//                     bucket count/offset tables, scatter of the point indices inside the bin's
+//                     (L2-resident) span of `sorted`
+// No global atomics; every global access is a coalesced stream or a scatter confined to one bin.
+// ------------------------------------------------------------------------------------------
+constexpr int SORT_BLOCK = 256;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;   // digits per workgroup
+constexpr int COARSE_MAX = 128;                      // coarse bins per window (c <= 16, 8 fine bits)
+constexpr uint32_t DIGIT_ZERO = 0xFFFFu;
+
+template <bool FAST>
+__global__ void __launch_bounds__(256) k_digits(const uint8_t* __restrict__ scalars, Geom g, uint16_t* __restrict__ dig) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < g.W; ++w) {
+        uint32_t off = w * g.c;
+        uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
+        uint32_t raw = FAST ? scalar_bits32(reinterpret_cast<const uint32_t*>(scalars), g, i, g.bit_lo + off, nb)
+                            : scalar_bits(scalars, g, i, g.bit_lo + off, nb);
+        raw += carry;
+        bool negd = raw > g.half;
+        uint32_t mag = negd ? (1u << g.c) - raw : raw;
+        carry = negd ? 1u : 0u;
+        if ((w % g.nshards) == g.shard) {
+            uint32_t code = mag == 0 ? DIGIT_ZERO : ((negd ? 0x8000u : 0u) | (mag - 1));
+            dig[(size_t)(w / g.nshards) * g.n + i] = (uint16_t)code;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_coarse_hist(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
+                                                              uint32_t ntile, uint32_t* __restrict__ M) {
+    __shared__ uint32_t h[COARSE_MAX];
+    const uint32_t wl = blockIdx.y, tile = blockIdx.x;
+    if (threadIdx.x < COARSE_MAX) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint16_t* d = dig + (size_t)wl * n;
+    const uint32_t base = tile * SORT_TILE;
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
+        if (i < n) {
+            uint32_t code = d[i];
+            if (code != DIGIT_ZERO) atomicAdd(&h[(code & 0x7FFFu) >> fine_bits], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < cb) M[((size_t)wl * cb + threadIdx.x) * ntile + tile] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_coarse_scatter(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
+                                                                 uint32_t ntile, const uint32_t* __restrict__ Mscan, uint64_t* __restrict__ tmp) {
+    __shared__ uint32_t h[COARSE_MAX];        // counts, then running cursors
+    __shared__ uint32_t lstart[COARSE_MAX];   // start of each bin inside the staged tile
+    __shared__ uint32_t delta[COARSE_MAX];    // global position of slot s = delta[bin] + s
+    __shared__ uint64_t stage[SORT_TILE];
+    const uint32_t wl = blockIdx.y, tile = blockIdx.x;
+    if (threadIdx.x < COARSE_MAX) h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint16_t* d = dig + (size_t)wl * n;
+    const uint32_t base = tile * SORT_TILE;
+    uint32_t codes[SORT_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
+        codes[k] = i < n ? (uint32_t)d[i] : DIGIT_ZERO;
+        if (codes[k] != DIGIT_ZERO) atomicAdd(&h[(codes[k] & 0x7FFFu) >> fine_bits], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the (<= 128) bin counts by the first two waves
+    if (threadIdx.x < COARSE_MAX) lstart[threadIdx.x] = threadIdx.x < cb ? h[threadIdx.x] : 0;
+    __syncthreads();
+    for (int dd = 1; dd < COARSE_MAX; dd <<= 1) {
+        uint32_t t = 0;
+        if (threadIdx.x < COARSE_MAX && (int)threadIdx.x >= dd) t = lstart[threadIdx.x - dd];
+        __syncthreads();
+        if (threadIdx.x < COARSE_MAX) lstart[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t incl = 0, cntb = 0;
+    if (threadIdx.x < COARSE_MAX) {
+        incl = lstart[threadIdx.x];
+        cntb = threadIdx.x < cb ? h[threadIdx.x] : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < COARSE_MAX) {
+        uint32_t excl = incl - cntb;
+        lstart[threadIdx.x] = excl;
+        if (threadIdx.x < cb) delta[threadIdx.x] = Mscan[((size_t)wl * cb + threadIdx.x) * ntile + tile] - excl;   // mod 2^32
+        h[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const uint32_t total = lstart[cb - 1];   // start of the last bin; its count is added below
+#pragma unroll
+    for (int k = 0; k < SORT_ITEMS; ++k) {
+        if (codes[k] != DIGIT_ZERO) {
+            uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
+            uint32_t b = codes[k] & 0x7FFFu;
+            uint32_t bin = b >> fine_bits;
+            uint32_t fine = b & ((1u << fine_bits) - 1u);
+            uint32_t r = atomicAdd(&h[bin], 1u);
+            uint64_t e = ((uint64_t)bin << 40) | ((uint64_t)fine << 32) | (uint64_t)(i | ((codes[k] & 0x8000u) << 16));
+            stage[lstart[bin] + r] = e;
+        }
+    }
+    __syncthreads();
+    const uint32_t staged = total + h[cb - 1];
+    for (uint32_t s = threadIdx.x; s < staged; s += SORT_BLOCK) {
+        uint64_t e = stage[s];
+        uint32_t bin = (uint32_t)(e >> 40);
+        tmp[(uint32_t)(delta[bin] + s)] = e;
+    }
+}
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_fine_sort(const uint64_t* __restrict__ tmp, const uint32_t* __restrict__ Mscan, uint32_t ntile,
+                                                            uint32_t nbins_total, uint32_t fine_bits, uint32_t cb, uint32_t half,
+                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ count, uint32_t* __restrict__ offset) {
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t lofs[256];
+    const uint32_t bin = blockIdx.x;                       // = wl * cb + coarse bin
+    const uint32_t start = Mscan[(size_t)bin * ntile];
+    const uint32_t end = Mscan[(size_t)(bin + 1) * ntile];   // the scan carries one extra element = total
+    const uint32_t nf = 1u << fine_bits;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t p = start + threadIdx.x; p < end; p += SORT_BLOCK) atomicAdd(&h[(uint32_t)(tmp[p] >> 32) & 0xFFu], 1u);
+    __syncthreads();
+    uint32_t v = h[threadIdx.x];
+    lofs[threadIdx.x] = v;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+        uint32_t t = (int)threadIdx.x >= dd ? lofs[threadIdx.x - dd] : 0;
+        __syncthreads();
+        lofs[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t excl = lofs[threadIdx.x] - v;
+    __syncthreads();
+    lofs[threadIdx.x] = excl;
+    h[threadIdx.x] = 0;
+    if (threadIdx.x < nf) {
+        uint32_t wl = bin / cb, cbin = bin % cb;
+        uint32_t gb = wl * half + (cbin << fine_bits) + threadIdx.x;
+        count[gb] = v;
+        offset[gb] = start + excl;
+    }
+    __syncthreads();
+    for (uint32_t p = start + threadIdx.x; p < end; p += SORT_BLOCK) {
+        uint64_t e = tmp[p];
+        uint32_t f = (uint32_t)(e >> 32) & 0xFFu;
+        uint32_t r = atomicAdd(&h[f], 1u);
+        sorted[start + lofs[f] + r] = (uint32_t)e;
+    }
+    (void)nbins_total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -418,6 +586,9 @@ struct msm_amd_ctx {
     hipEvent_t ev[8] = {};
     std::string err;
     uint32_t force_c = 0;
+    uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
+    DevBuf d_dig, d_tmp, d_M, d_Mscan;
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
@@ -499,7 +670,7 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
-    if (c > 22) c = 22;
+    if (c > 16) c = 16;   // 16-bit digit codes, 15-bit bucket index
     return c;
 }
 
@@ -518,8 +689,7 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);
     for (float& t : ctx->timings) t = 0.f;
     if (a.n == 0 || a.nbits == 0) {
-        X inf = X::inf();
-        host_store_jacobian_normalised(inf, out);
+        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
         return 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -566,8 +736,7 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     ctx->geometry[3] = g.Wl;
     ctx->geometry[4] = ctx->geometry[5] = 0;
     if (g.Wl == 0) {
-        X inf = X::inf();
-        host_store_jacobian_normalised(inf, out);
+        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
         return 0;
     }
     const uint32_t NB = g.Wl * g.half;
@@ -600,31 +769,68 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     uint32_t* tiles = (uint32_t*)ctx->d_tiles.p;
     uint32_t* sorted = (uint32_t*)ctx->d_sorted.p;
 
-    // ---- 1. digits + histogram
-    HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_BINS * 4, st));
     const uint32_t nblk = (a.n + 255) / 256;
-    if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
-    else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
-    HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
-    // ---- 2. scan + order
-    k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
-    k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
-    k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
     const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
-    k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
-    k_order_scan<<<1, 1024, 0, st>>>(bins);
-    k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
-    HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
-    // ---- 3. scatter
-    if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
-    else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
-    HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_BINS * 4, st));
+    if (ctx->sort_atomic) {
+        // ---- 1. digits + histogram (global atomics)
+        HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
+        if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+        else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+        // ---- 2. scan + order
+        k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
+        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
+        k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
+        k_order_scan<<<1, 1024, 0, st>>>(bins);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+        // ---- 3. scatter
+        if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+        else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    } else {
+        // ---- 1. digit codes + coarse histogram
+        const uint32_t fine_bits = std::min(8u, g.c - 1);
+        const uint32_t cb = g.half >> fine_bits;                      // coarse bins per window (<= 128)
+        const uint32_t stile = (a.n + SORT_TILE - 1) / SORT_TILE;
+        const size_t NM = (size_t)g.Wl * cb * stile;                   // count matrix entries (+1 for the total)
+        const uint32_t mtiles = (uint32_t)((NM + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        if (int rc = ensure(ctx, ctx->d_dig, (size_t)g.Wl * a.n * 2)) return rc;
+        if (int rc = ensure(ctx, ctx->d_tmp, (size_t)g.Wl * a.n * 8)) return rc;
+        if (int rc = ensure(ctx, ctx->d_M, (NM + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, ctx->d_Mscan, (NM + 1) * 4 * 2)) return rc;
+        if (int rc = ensure(ctx, ctx->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
+        tiles = (uint32_t*)ctx->d_tiles.p;
+        uint16_t* dig = (uint16_t*)ctx->d_dig.p;
+        uint64_t* tmp = (uint64_t*)ctx->d_tmp.p;
+        uint32_t* M = (uint32_t*)ctx->d_M.p;
+        uint32_t* Mscan = (uint32_t*)ctx->d_Mscan.p;
+        uint32_t* Mdummy = Mscan + (NM + 1);
+        if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
+        k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, M);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+        // ---- 2. scan of the count matrix
+        k_scan_tile_sums<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles);
+        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, mtiles);
+        k_scan_apply<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles, Mscan, Mdummy);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+        // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
+        k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, Mscan, tmp);
+        k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
+        k_order_scan<<<1, 1024, 0, st>>>(bins);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
+        HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+    }
     // ---- 4. accumulate
     k_accumulate<F><<<(NB + 255) / 256, 256, 0, st>>>(d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p);
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
     // ---- 5. reduce
-    uint32_t L = std::max(1u, g.half / 8192u);
+    uint32_t L = ctx->force_L ? ctx->force_L : std::max(1u, g.half / 4096u);
     uint32_t lanes_per_window = (g.half + L - 1) / L;
     uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
     // LDS budget: rblock * XSZ must fit in 64 KB (default limit); shrink for wide fields
@@ -658,19 +864,22 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
 
     // ---- 6. host combine: window sums, Horner over owned windows (top first), each weighted 2^(c*w)
     auto t0 = std::chrono::steady_clock::now();
-    const X* parts = reinterpret_cast<const X*>(ctx->h_partials);
-    X total = X::inf();
+    using HF = typename HostOf<F>::type;
+    using HX = XYZZ<HF>;
+    static_assert(sizeof(HX) == sizeof(X), "host twin has the same byte image");
+    const HX* parts = reinterpret_cast<const HX*>(ctx->h_partials);
+    HX total = HX::inf();
     int prev_w = -1;   // global index of the window most recently folded in
     for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
         int wglob = wl * (int)g.nshards + (int)g.shard;
         if (prev_w >= 0)
-            for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = X::dbl(total);
-        X s = X::inf();
-        for (uint32_t k = 0; k < wgs_per_window; ++k) s = X::add(s, parts[(size_t)wl * wgs_per_window + k]);
-        total = X::add(total, s);
+            for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = HX::dbl(total);
+        HX s = HX::inf();
+        for (uint32_t k = 0; k < wgs_per_window; ++k) s = HX::add(s, parts[(size_t)wl * wgs_per_window + k]);
+        total = HX::add(total, s);
         prev_w = wglob;
     }
-    for (int k = 0; k < prev_w * (int)g.c; ++k) total = X::dbl(total);
+    for (int k = 0; k < prev_w * (int)g.c; ++k) total = HX::dbl(total);
     if (a.raw_out) host_store_jacobian_raw(total, out);
     else host_store_jacobian_normalised(total, out);
     auto t1 = std::chrono::steady_clock::now();
@@ -755,6 +964,9 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     msm_amd_ctx* ctx = new (std::nothrow) msm_amd_ctx();
     if (!ctx) return MSM_AMD_ENOMEM;
     ctx->device = device_id;
+    if (const char* e = getenv("MSM_AMD_REDUCE_L")) ctx->force_L = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return MSM_AMD_EHIP;
@@ -772,7 +984,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
+    for (DevBuf* b : {&ctx->d_dig, &ctx->d_tmp, &ctx->d_M, &ctx->d_Mscan, &ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
                       &ctx->d_tiles, &ctx->d_sorted, &ctx->d_buckets, &ctx->d_partials})
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
@@ -785,7 +997,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
 const char* msm_amd_last_error(const msm_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
-    if (!ctx || c > 22) return MSM_AMD_EINVAL;
+    if (!ctx || c > 16) return MSM_AMD_EINVAL;
     ctx->force_c = c;
     return 0;
 }
@@ -817,10 +1029,10 @@ int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
 
 #define BY_FIELD(curve, group, CALL)                                                         \
     do {                                                                                     \
-        if ((curve) == MSM_AMD_BLS12381 && (group) == 1) { using F = Fp<Bls12381Fp>; CALL; }  \
-        if ((curve) == MSM_AMD_BLS12381 && (group) == 2) { using F = Fp2<Bls12381Fp>; CALL; } \
-        if ((curve) == MSM_AMD_BN128 && (group) == 1) { using F = Fp<Bn254Fp>; CALL; }        \
-        if ((curve) == MSM_AMD_BN128 && (group) == 2) { using F = Fp2<Bn254Fp>; CALL; }       \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 1) { using F = FpH<Bls12381Fp>; CALL; }        \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 2) { using F = Fp2T<FpH<Bls12381Fp>>; CALL; }  \
+        if ((curve) == MSM_AMD_BN128 && (group) == 1) { using F = FpH<Bn254Fp>; CALL; }              \
+        if ((curve) == MSM_AMD_BN128 && (group) == 2) { using F = Fp2T<FpH<Bn254Fp>>; CALL; }        \
     } while (0)
 
 int msm_amd_combine(int curve, int group, const uint8_t* partials, uint32_t count, uint8_t* out) {
@@ -856,14 +1068,14 @@ int msm_amd_eq(int curve, int group, const uint8_t* jac_a, const uint8_t* jac_b)
 }
 int msm_amd_f_to_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
     if (!in || !out) return MSM_AMD_EINVAL;
-    if (curve == MSM_AMD_BLS12381) return f_conv<Fp<Bls12381Fp>, true>(in, count, out);
-    if (curve == MSM_AMD_BN128) return f_conv<Fp<Bn254Fp>, true>(in, count, out);
+    if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, true>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, true>(in, count, out);
     return MSM_AMD_EINVAL;
 }
 int msm_amd_f_from_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
     if (!in || !out) return MSM_AMD_EINVAL;
-    if (curve == MSM_AMD_BLS12381) return f_conv<Fp<Bls12381Fp>, false>(in, count, out);
-    if (curve == MSM_AMD_BN128) return f_conv<Fp<Bn254Fp>, false>(in, count, out);
+    if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, false>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, false>(in, count, out);
     return MSM_AMD_EINVAL;
 }
 
