@@ -1,0 +1,6 @@
+// Bucket kernels for BLS12-381 G1 (381-bit Fp, multiplies expanded inline).
+#include "bucket_kernels.hpp"
+namespace msm {
+using F_ = Fp<Bls12381Fp, true>;
+MSM_INSTANTIATE_BUCKET_KERNELS(F_)
+}  // namespace msm

@@ -41,8 +41,14 @@ struct XYZZ {
         return {p.x, p.y, F::one(), F::one()};
     }
 
-    // 2*(x,y) for an affine, non-infinite point (mdbl-2008-s-1, a = 0)
-    MSM_HD static XYZZ dbl_affine(const F& x, const F& y) {
+    // 2*(x,y) for an affine, non-infinite point (mdbl-2008-s-1, a = 0).  Rare on the hot path (only
+    // when a bucket meets the same point twice in a row), so kept out of line on the device.
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __noinline__ static XYZZ dbl_affine(F x, F y) { return dbl_affine_inl(x, y); }
+#else
+    static XYZZ dbl_affine(const F& x, const F& y) { return dbl_affine_inl(x, y); }
+#endif
+    MSM_HD static XYZZ dbl_affine_inl(const F& x, const F& y) {
         F U = F::dbl(y);
         F V = F::sqr(U);
         F W = F::mul(U, V);
@@ -115,6 +121,10 @@ struct XYZZ {
         F ZZZ3 = F::mul(F::mul(a.zzz, b.zzz), PPP);
         return {X3, Y3, ZZ3, ZZZ3};
     }
+
+    // out-of-line forms for kernels that chain many full additions (bucket reduction)
+    __device__ __noinline__ static XYZZ add_ni(XYZZ a, XYZZ b) { return add(a, b); }
+    __device__ __noinline__ static XYZZ dbl_ni(XYZZ a) { return dbl(a); }
 
     MSM_HD static XYZZ neg(const XYZZ& p) { return {p.x, F::neg(p.y), p.zz, p.zzz}; }
 

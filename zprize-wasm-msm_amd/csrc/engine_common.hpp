@@ -1,0 +1,54 @@
+// engine_common.hpp -- helpers shared by the engine's translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "curve.hpp"
+
+namespace msm {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+template <class T>
+MSM_D T load16(const void* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+    T t;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint32_t* d = reinterpret_cast<uint32_t*>(&t);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) {
+        uint4 q = s[k];
+        d[4 * k + 0] = q.x;
+        d[4 * k + 1] = q.y;
+        d[4 * k + 2] = q.z;
+        d[4 * k + 3] = q.w;
+    }
+    return t;
+}
+template <class T>
+MSM_D void store16(void* p, const T& t) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
+    uint4* s = reinterpret_cast<uint4*>(p);
+    const uint32_t* d = reinterpret_cast<const uint32_t*>(&t);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) s[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
+}
+
+// Window geometry shared by host and kernels.
+struct Geom {
+    uint32_t n;
+    uint32_t scalar_size;   // bytes per scalar
+    uint32_t bit_lo;        // first bit of the scalar range
+    uint32_t nbits;         // bits in the range (after clipping to the scalar end)
+    uint32_t c;             // window bits
+    uint32_t W;             // number of windows = nbits / c + 1 (the last one absorbs the carry)
+    uint32_t half;          // buckets per window = 2^(c-1)
+    uint32_t shard, nshards;   // this call owns windows w with w % nshards == shard
+    uint32_t Wl;            // number of owned windows
+};
+
+
+}  // namespace msm

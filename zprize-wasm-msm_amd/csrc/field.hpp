@@ -49,7 +49,10 @@ MSM_HD void mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 #endif
 }
 
-template <class P>
+// INL = true: multiplies are expanded inline at every use (the G1 bucket kernels: no call overhead,
+// no spills around calls); INL = false: one out-of-line body per translation unit (small code).
+// Both flavours have the same layout and value semantics.
+template <class P, bool INL = false>
 struct Fp {
     static constexpr int N = P::N;
     static constexpr int BYTES = 4 * P::N;
@@ -219,10 +222,16 @@ struct Fp {
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-    // Out-of-line on the device: one ~5 KB body shared by every call site keeps the bucket
-    // kernels inside the instruction cache.
-    __device__ __noinline__ static Fp mul(Fp a, Fp b) { return mul_inl(a, b); }
-    __device__ __noinline__ static Fp sqr(Fp a) { return sqr_inl(a); }
+    __device__ __noinline__ static Fp mul_ni(Fp a, Fp b) { return mul_inl(a, b); }
+    __device__ __noinline__ static Fp sqr_ni(Fp a) { return sqr_inl(a); }
+    MSM_D static Fp mul(const Fp& a, const Fp& b) {
+        if constexpr (INL) return mul_inl(a, b);
+        else return mul_ni(a, b);
+    }
+    MSM_D static Fp sqr(const Fp& a) {
+        if constexpr (INL) return sqr_inl(a);
+        else return sqr_ni(a);
+    }
 #else
     static Fp mul(const Fp& a, const Fp& b) { return mul_inl(a, b); }
     static Fp sqr(const Fp& a) { return sqr_inl(a); }

@@ -142,12 +142,12 @@ struct FpH {
 // device field type -> host twin with the same byte image
 template <class F>
 struct HostOf;
-template <class P>
-struct HostOf<Fp<P>> {
+template <class P, bool I>
+struct HostOf<Fp<P, I>> {
     using type = FpH<P>;
 };
-template <class P>
-struct HostOf<Fp2T<Fp<P>>> {
+template <class P, bool I>
+struct HostOf<Fp2T<Fp<P, I>>> {
     using type = Fp2T<FpH<P>>;
 };
 

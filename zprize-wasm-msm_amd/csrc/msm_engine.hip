@@ -28,50 +28,27 @@
 #include <vector>
 
 #include "../../include/msm_amd.h"
-#include "curve.hpp"
+#include "engine_common.hpp"
 #include "field_host.hpp"
 
 namespace msm {
 
-// ------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------
-template <class T>
-MSM_D T load16(const void* p) {
-    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
-    T t;
-    const uint4* s = reinterpret_cast<const uint4*>(p);
-    uint32_t* d = reinterpret_cast<uint32_t*>(&t);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) {
-        uint4 q = s[k];
-        d[4 * k + 0] = q.x;
-        d[4 * k + 1] = q.y;
-        d[4 * k + 2] = q.z;
-        d[4 * k + 3] = q.w;
-    }
-    return t;
-}
-template <class T>
-MSM_D void store16(void* p, const T& t) {
-    static_assert(sizeof(T) % 16 == 0, "16-byte granules");
-    uint4* s = reinterpret_cast<uint4*>(p);
-    const uint32_t* d = reinterpret_cast<const uint32_t*>(&t);
-#pragma unroll
-    for (int k = 0; k < (int)(sizeof(T) / 16); ++k) s[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
-}
 
-// Window geometry shared by host and kernels.
-struct Geom {
-    uint32_t n;
-    uint32_t scalar_size;   // bytes per scalar
-    uint32_t bit_lo;        // first bit of the scalar range
-    uint32_t nbits;         // bits in the range (after clipping to the scalar end)
-    uint32_t c;             // window bits
-    uint32_t W;             // number of windows = nbits / c + 1 (the last one absorbs the carry)
-    uint32_t half;          // buckets per window = 2^(c-1)
-    uint32_t shard, nshards;   // this call owns windows w with w % nshards == shard
-    uint32_t Wl;            // number of owned windows
+// launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
+template <class F>
+void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets);
+template <class F>
+void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
+                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials);
+// field flavour used inside the bucket kernels: G1 fields expand their multiplies inline
+template <class F>
+struct KernelField {
+    using type = F;
+};
+template <class P>
+struct KernelField<Fp<P, false>> {
+    using type = Fp<P, true>;
 };
 
 // Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
@@ -430,80 +407,6 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------
-// stage 4: bucket accumulation -- one lane per bucket
-// ------------------------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                     const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
-                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nb) return;
-    uint32_t b = order[r];
-    uint32_t cnt = count[b];
-    uint32_t off = offset[b];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t e = sorted[off + k];
-        uint32_t idx = e & 0x7fffffffu;
-        Affine<F> p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
-        bool inf = p.is_inf();
-        p.y = F::cneg(p.y, (e >> 31) != 0 && !inf);
-        XYZZ<F>::madd(acc, p.x, p.y);
-    }
-    store16(buckets + (size_t)b * sizeof(XYZZ<F>), acc);
-}
-
-// ------------------------------------------------------------------------------------------
-// stage 5: bucket reduction  S_w = sum_{k=1..half} k * B[w][k-1]
-// Lane t of window w owns buckets [t*L, t*L+L): running sums give sum_j (j+1) B[t*L+j] and
-// A = sum_j B[t*L+j]; adding (t*L)*A (double-and-add) makes the lane's share exact; a workgroup
-// tree in LDS then leaves one partial per workgroup.
-// ------------------------------------------------------------------------------------------
-template <class F>
-__global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
-                                                        uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
-    uint32_t w = blockIdx.x / wgs_per_window;
-    uint32_t wg = blockIdx.x % wgs_per_window;
-    uint32_t t = wg * blockDim.x + threadIdx.x;
-    XYZZ<F> res = XYZZ<F>::inf();
-    if (t < lanes_per_window) {
-        uint32_t base = t * L;
-        XYZZ<F> run = XYZZ<F>::inf();
-        XYZZ<F> sum = XYZZ<F>::inf();
-        for (int j = (int)L - 1; j >= 0; --j) {
-            if (base + j < half) {
-                XYZZ<F> bk = load16<XYZZ<F>>(buckets + ((size_t)w * half + base + j) * sizeof(XYZZ<F>));
-                run = XYZZ<F>::add(run, bk);
-            }
-            sum = XYZZ<F>::add(sum, run);
-        }
-        // res = sum + base * run
-        XYZZ<F> m = XYZZ<F>::inf();
-        if (base != 0) {
-            int top = 31 - __clz(base);
-            for (int bit = top; bit >= 0; --bit) {
-                m = XYZZ<F>::dbl(m);
-                if ((base >> bit) & 1u) m = XYZZ<F>::add(m, run);
-            }
-        }
-        res = XYZZ<F>::add(sum, m);
-    }
-    sh[threadIdx.x] = res;
-    __syncthreads();
-    for (int d = blockDim.x / 2; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
-            XYZZ<F> a = sh[threadIdx.x];
-            XYZZ<F> bb = sh[threadIdx.x + d];
-            sh[threadIdx.x] = XYZZ<F>::add(a, bb);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) store16(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>), sh[0]);
-}
-
-// ------------------------------------------------------------------------------------------
 // Jacobian bases -> affine (g?m_multiexp entry point): Montgomery's trick, 8 points per lane
 // (build_curve_jacobian_a0.js:1040-1125 batchToAffine does the same thing sequentially).
 // ------------------------------------------------------------------------------------------
@@ -827,7 +730,8 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
     }
     // ---- 4. accumulate
-    k_accumulate<F><<<(NB + 255) / 256, 256, 0, st>>>(d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p);
+    using FK = typename KernelField<F>::type;
+    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p);
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
     // ---- 5. reduce
     uint32_t L = ctx->force_L ? ctx->force_L : std::max(1u, g.half / 4096u);
@@ -845,8 +749,8 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         HIPCHK(ctx, hipHostMalloc(&ctx->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
         ctx->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
     }
-    k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * XSZ, st>>>((const uint8_t*)ctx->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
-                                                                   (uint8_t*)ctx->d_partials.p);
+    launch_bucket_reduce<FK>(st, nparts, rblock, (const uint8_t*)ctx->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
+                             (uint8_t*)ctx->d_partials.p);
     HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, st));
     // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
