@@ -64,6 +64,10 @@ void msm_amd_destroy(msm_amd_ctx *ctx);
 const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 /* Optional tuning: window size c in bits (0 = automatic). */
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
+/* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
+ * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
+ * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition). */
+int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 
 /* ---- generic entry points -------------------------------------------------------------------- */
 /* R = sum_i scalar_i * base_i                                 (build_multiexp.js:251-371) */

@@ -117,6 +117,34 @@ def test_adversarial_single_bucket(eng, orc):
     assert C.g1m_multiexpAffine(bases2, scalars, 32, n) == exp2
 
 
+@pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 1), ("bls12381", 2)])
+def test_long_buckets_are_segmented(eng, orc, curve, group):
+    """Force the long-bucket path (segment length 4): buckets are cut into segments summed by the tail
+    kernels; also the natural trigger -- all scalars equal at a size where one lane per bucket would crawl."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    n = 3000
+    bases, scalars = gu.random_case(curve, group, f"gpu:seg:{curve}:{group}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    eng.set_option("segment", 4)
+    eng.set_window_bits(6)
+    try:
+        assert _fn(C, group, True)(bases, scalars, 32, n) == exp
+        same = scalars[:32] * n
+        exp2 = O.normalize(O.multiexp_affine(bases, same, 32, n))
+        assert _fn(C, group, True)(bases, same, 32, n) == exp2
+    finally:
+        eng.set_option("segment", 0)
+        eng.set_window_bits(0)
+    # natural trigger at default settings: all scalars equal, n = 2^15 (one bucket per window holds everything)
+    if group == 1:
+        m = 1 << 15
+        b2 = (bases * (m // n + 1))[:m * C.affine_bytes(group)]
+        same = scalars[:32] * m
+        exp3 = O.normalize(O.multiexp_affine(b2, same, 32, m))
+        assert _fn(C, group, True)(b2, same, 32, m) == exp3
+
+
 def test_error_codes(eng):
     import msm_amd
     C = eng.curve("bls12381")

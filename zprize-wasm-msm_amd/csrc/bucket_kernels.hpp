@@ -8,27 +8,95 @@
 namespace msm {
 
 // ------------------------------------------------------------------------------------------
-// stage 4: bucket accumulation -- one lane per bucket
+// stage 4: bucket accumulation -- one lane per bucket.
+// A lane adds at most `seg` entries of its bucket (seg >= 4x the mean population, so random inputs
+// never exceed it).  A longer bucket -- adversarial scalars, e.g. all equal -- is cut into further
+// segments that the lane appends to a work list; k_accumulate_tail sums those segments with one
+// lane each and k_combine_tail folds them back into the bucket.  With no long bucket the two tail
+// kernels find empty lists and return.
 // ------------------------------------------------------------------------------------------
+struct TailCtl {
+    uint32_t nwork;   // segments queued
+    uint32_t nbig;    // buckets that queued segments
+    uint32_t pad[2];
+};
+
 template <class F>
-__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                     const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
-                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nb) return;
-    uint32_t b = order[r];
-    uint32_t cnt = count[b];
-    uint32_t off = offset[b];
+MSM_D XYZZ<F> accumulate_span(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t first, uint32_t len) {
     XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t k = 0; k < cnt; ++k) {
-        uint32_t e = sorted[off + k];
+    for (uint32_t k = 0; k < len; ++k) {
+        uint32_t e = sorted[first + k];
         uint32_t idx = e & 0x7fffffffu;
         Affine<F> p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
         bool inf = p.is_inf();
         p.y = F::cneg(p.y, (e >> 31) != 0 && !inf);
         XYZZ<F>::madd(acc, p.x, p.y);
     }
+    return acc;
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                     const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
+                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
+                                                     TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb) return;
+    uint32_t b = order[r];
+    uint32_t cnt = count[b];
+    uint32_t off = offset[b];
+    XYZZ<F> acc = accumulate_span<F>(bases, sorted, off, min(cnt, seg));
     store16(buckets + (size_t)b * sizeof(XYZZ<F>), acc);
+    if (cnt > seg) {
+        uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
+        uint32_t base = atomicAdd(&ctl->nwork, extra);
+        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
+        biglist[bi] = make_uint4(b, base, extra, 0u);
+        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, (j + 1) * seg);
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                          const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
+                                                          const TailCtl* __restrict__ ctl, const uint2* __restrict__ work, uint32_t seg,
+                                                          uint8_t* __restrict__ seg_out) {
+    const uint32_t nwork = ctl->nwork;
+    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < nwork; item += gridDim.x * blockDim.x) {
+        uint2 w = work[item];
+        uint32_t len = min(seg, count[w.x] - w.y);
+        XYZZ<F> acc = accumulate_span<F>(bases, sorted, offset[w.x] + w.y, len);
+        store16(seg_out + (size_t)item * sizeof(XYZZ<F>), acc);
+    }
+}
+
+template <class F>
+__global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict__ ctl, const uint4* __restrict__ biglist,
+                                                       const uint8_t* __restrict__ seg_out, uint8_t* __restrict__ buckets) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    const uint32_t nbig = ctl->nbig;
+    for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        uint4 d = biglist[bi];   // bucket, first segment, number of segments
+        XYZZ<F> loc = XYZZ<F>::inf();
+        for (uint32_t j = threadIdx.x; j < d.z; j += blockDim.x)
+            loc = XYZZ<F>::add_ni(loc, load16<XYZZ<F>>(seg_out + (size_t)(d.y + j) * sizeof(XYZZ<F>)));
+        sh[threadIdx.x] = loc;
+        __syncthreads();
+        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) {
+                XYZZ<F> a = sh[threadIdx.x];
+                XYZZ<F> bb = sh[threadIdx.x + s];
+                sh[threadIdx.x] = XYZZ<F>::add_ni(a, bb);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            XYZZ<F> cur = load16<XYZZ<F>>(buckets + (size_t)d.x * sizeof(XYZZ<F>));
+            store16(buckets + (size_t)d.x * sizeof(XYZZ<F>), XYZZ<F>::add_ni(cur, sh[0]));
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -37,6 +105,28 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ 
 // A = sum_j B[t*L+j]; adding (t*L)*A (double-and-add) makes the lane's share exact; a workgroup
 // tree in LDS then leaves one partial per workgroup.
 // ------------------------------------------------------------------------------------------
+// Full additions inside the reduction: expanded inline for the G1 fields (the kernel runs one wave per
+// SIMD and is latency-bound; calls would spill the three live points around every addition), out of
+// line for Fp2 where the inlined body would be ~3x larger.
+template <class F>
+struct InlineAdds {
+    static constexpr bool value = false;
+};
+template <class P>
+struct InlineAdds<Fp<P, true>> {
+    static constexpr bool value = true;
+};
+template <class F>
+MSM_D XYZZ<F> radd(const XYZZ<F>& a, const XYZZ<F>& b) {
+    if constexpr (InlineAdds<F>::value) return XYZZ<F>::add(a, b);
+    else return XYZZ<F>::add_ni(a, b);
+}
+template <class F>
+MSM_D XYZZ<F> rdbl(const XYZZ<F>& a) {
+    if constexpr (InlineAdds<F>::value) return XYZZ<F>::dbl(a);
+    else return XYZZ<F>::dbl_ni(a);
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
                                                         uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
@@ -53,20 +143,20 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
         for (int j = (int)L - 1; j >= 0; --j) {
             if (base + j < half) {
                 XYZZ<F> bk = load16<XYZZ<F>>(buckets + ((size_t)w * half + base + j) * sizeof(XYZZ<F>));
-                run = XYZZ<F>::add_ni(run, bk);
+                run = radd<F>(run, bk);
             }
-            sum = XYZZ<F>::add_ni(sum, run);
+            sum = radd<F>(sum, run);
         }
         // res = sum + base * run
         XYZZ<F> m = XYZZ<F>::inf();
         if (base != 0) {
             int top = 31 - __clz(base);
             for (int bit = top; bit >= 0; --bit) {
-                m = XYZZ<F>::dbl_ni(m);
-                if ((base >> bit) & 1u) m = XYZZ<F>::add_ni(m, run);
+                m = rdbl<F>(m);
+                if ((base >> bit) & 1u) m = radd<F>(m, run);
             }
         }
-        res = XYZZ<F>::add_ni(sum, m);
+        res = radd<F>(sum, m);
     }
     sh[threadIdx.x] = res;
     __syncthreads();
@@ -74,7 +164,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
         if ((int)threadIdx.x < d) {
             XYZZ<F> a = sh[threadIdx.x];
             XYZZ<F> bb = sh[threadIdx.x + d];
-            sh[threadIdx.x] = XYZZ<F>::add_ni(a, bb);
+            sh[threadIdx.x] = radd<F>(a, bb);
         }
         __syncthreads();
     }
@@ -84,8 +174,12 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 
 template <class F>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets) {
-    k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, sorted, offset, count, order, nb, buckets);
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
+                       uint32_t tail_block) {
+    k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
+                                                       (uint4*)biglist);
+    k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
+    k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(XYZZ<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
@@ -95,7 +189,7 @@ void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, cons
 
 #define MSM_INSTANTIATE_BUCKET_KERNELS(F)                                                                                                   \
     template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,   \
-                                       uint32_t, uint8_t*);                                                                                 \
+                                       uint32_t, uint8_t*, uint32_t, void*, void*, void*, uint8_t*, uint32_t);                              \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*);
 
 }  // namespace msm

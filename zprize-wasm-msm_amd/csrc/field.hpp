@@ -92,6 +92,13 @@ struct Fp {
 
     // r = a - q if a >= q else a   (a < 2q, carry = bit 32N of a)
     MSM_HD static Fp reduce_once(const Fp& a, uint32_t carry) {
+#if 0 && defined(__HIP_DEVICE_COMPILE__)
+        // a < 2q < 2^(32N) for both supported moduli, so bit 32N (carry) is never set
+        (void)carry;
+        Fp r = a;
+        FpAsm<P>::reduce(r.v);
+        return r;
+#else
         Fp d;
         uint64_t br = 0;
 #pragma unroll
@@ -105,10 +112,17 @@ struct Fp {
 #pragma unroll
         for (int i = 0; i < N; ++i) r.v[i] = use_d ? d.v[i] : a.v[i];
         return r;
+#endif
     }
 
     // build_f1m.js:71-89
     MSM_HD static Fp add(const Fp& a, const Fp& b) {
+#if 0 && defined(__HIP_DEVICE_COMPILE__)
+        Fp r;
+        (void)FpAsm<P>::add_raw(r.v, a.v, b.v);   // a + b < 2q < 2^(32N): no carry out
+        FpAsm<P>::reduce(r.v);
+        return r;
+#else
         Fp s;
         uint64_t c = 0;
 #pragma unroll
@@ -118,10 +132,17 @@ struct Fp {
             c = t >> 32;
         }
         return reduce_once(s, (uint32_t)c);
+#endif
     }
     MSM_HD static Fp dbl(const Fp& a) { return add(a, a); }
     // build_f1m.js:91-105
     MSM_HD static Fp sub(const Fp& a, const Fp& b) {
+#if 0 && defined(__HIP_DEVICE_COMPILE__)
+        Fp r;
+        uint64_t borrow = FpAsm<P>::sub_raw(r.v, a.v, b.v);
+        FpAsm<P>::add_q_masked(r.v, borrow);
+        return r;
+#else
         Fp d;
         uint64_t br = 0;
 #pragma unroll
@@ -139,15 +160,22 @@ struct Fp {
             c = t >> 32;
         }
         return d;
+#endif
     }
     // build_f1m.js:107-117 (0 - x; neg(0) == 0)
-    MSM_HD static Fp neg(const Fp& a) { return sub(zero(), a); }
+    MSM_HD static Fp neg(const Fp& a) { return cneg(a, true); }
     MSM_HD static Fp cneg(const Fp& a, bool flag) {
-        Fp n = neg(a);
+#if 0 && defined(__HIP_DEVICE_COMPILE__)
+        Fp r = a;
+        FpAsm<P>::rsub_q_masked(r.v, __ballot(flag && !a.is_zero()));   // q - a on the flagged lanes; -0 = 0
+        return r;
+#else
+        Fp n = sub(zero(), a);
         Fp r;
 #pragma unroll
         for (int i = 0; i < N; ++i) r.v[i] = flag ? n.v[i] : a.v[i];
         return r;
+#endif
     }
 
     // build_f1m.js:466-777 -- Montgomery product a*b*R^-1 mod q, fully reduced.

@@ -37,7 +37,8 @@ namespace msm {
 // launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
 template <class F>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets);
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
+                       uint32_t tail_block);
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials);
@@ -489,9 +490,10 @@ struct msm_amd_ctx {
     hipEvent_t ev[8] = {};
     std::string err;
     uint32_t force_c = 0;
+    uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
-    DevBuf d_dig, d_tmp, d_M, d_Mscan;
+    DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
@@ -731,7 +733,18 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     }
     // ---- 4. accumulate
     using FK = typename KernelField<F>::type;
-    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p);
+    // segment length: >= 4x the mean bucket population (random inputs never split); long buckets are cut
+    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(128u, 4u * ((a.n + g.half - 1) / g.half));
+    const size_t max_segs = (size_t)g.Wl * a.n / seg + 1;
+    if (int rc = ensure(ctx, ctx->d_tailctl, sizeof(uint32_t) * 4)) return rc;
+    if (int rc = ensure(ctx, ctx->d_work, max_segs * 8)) return rc;
+    if (int rc = ensure(ctx, ctx->d_biglist, max_segs * 16)) return rc;
+    if (int rc = ensure(ctx, ctx->d_segout, max_segs * XSZ)) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_tailctl.p, 0, 16, st));
+    uint32_t tail_block = 256;
+    while ((size_t)tail_block * XSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
+    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p, seg, ctx->d_tailctl.p, ctx->d_work.p,
+                          ctx->d_biglist.p, (uint8_t*)ctx->d_segout.p, tail_block);
     HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
     // ---- 5. reduce
     uint32_t L = ctx->force_L ? ctx->force_L : std::max(1u, g.half / 4096u);
@@ -869,6 +882,7 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (!ctx) return MSM_AMD_ENOMEM;
     ctx->device = device_id;
     if (const char* e = getenv("MSM_AMD_REDUCE_L")) ctx->force_L = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -888,7 +902,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->d_dig, &ctx->d_tmp, &ctx->d_M, &ctx->d_Mscan, &ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
+    for (DevBuf* b : {&ctx->d_tailctl, &ctx->d_work, &ctx->d_biglist, &ctx->d_segout, &ctx->d_dig, &ctx->d_tmp, &ctx->d_M, &ctx->d_Mscan, &ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
                       &ctx->d_tiles, &ctx->d_sorted, &ctx->d_buckets, &ctx->d_partials})
         if (b->p) (void)hipFree(b->p);
     if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
@@ -899,6 +913,16 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
 }
 
 const char* msm_amd_last_error(const msm_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
+    if (!ctx || !name) return MSM_AMD_EINVAL;
+    if (!strcmp(name, "window_bits")) return msm_amd_set_window_bits(ctx, value);
+    if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
+    if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
+    if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
+    ctx->err = "unknown option";
+    return MSM_AMD_EINVAL;
+}
 
 int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
     if (!ctx || c > 16) return MSM_AMD_EINVAL;

@@ -52,6 +52,7 @@ def load_library(path=None):
     L.msm_amd_last_error.argtypes = [vp]
     L.msm_amd_last_error.restype = c.c_char_p
     L.msm_amd_set_window_bits.argtypes = [vp, u32]
+    L.msm_amd_set_option.argtypes = [vp, c.c_char_p, u32]
     L.msm_amd_multiexp.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
     L.msm_amd_multiexp_chunk.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_multiexp_shard.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
@@ -147,6 +148,9 @@ class Engine:
 
     def set_window_bits(self, c):
         self._chk(self.L.msm_amd_set_window_bits(self.ctx, int(c)))
+
+    def set_option(self, name, value):
+        self._chk(self.L.msm_amd_set_option(self.ctx, name.encode(), int(value)))
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
