@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store16(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>), sh[0]);
+    if (threadIdx.x == 0) store16(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>), XYZZ<F>::canon(sh[0]));   // leaves the GPU: canonical
 }
 
 

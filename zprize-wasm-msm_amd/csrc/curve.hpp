@@ -23,6 +23,7 @@ template <class F>
 struct Affine {
     F x, y;
     MSM_HD bool is_inf() const { return x.is_zero() && y.is_zero(); }
+    MSM_HD static Affine canon(const Affine& p) { return {F::canon(p.x), F::canon(p.y)}; }
 };
 
 template <class F>
@@ -93,7 +94,7 @@ struct XYZZ {
         F PP = F::sqr(Pd);
         F PPP = F::mul(Pd, PP);
         F Q = F::mul(acc.x, PP);
-        F X3 = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
+        F X3 = F::sub(F::sub(F::sub(F::sqr(Rd), PPP), Q), Q);
         F Y3 = F::sub(F::mul(Rd, F::sub(Q, X3)), F::mul(acc.y, PPP));
         acc.x = X3;
         acc.y = Y3;
@@ -115,7 +116,7 @@ struct XYZZ {
         F PP = F::sqr(Pd);
         F PPP = F::mul(Pd, PP);
         F Q = F::mul(U1, PP);
-        F X3 = F::sub(F::sub(F::sqr(Rd), PPP), F::dbl(Q));
+        F X3 = F::sub(F::sub(F::sub(F::sqr(Rd), PPP), Q), Q);
         F Y3 = F::sub(F::mul(Rd, F::sub(Q, X3)), F::mul(S1, PPP));
         F ZZ3 = F::mul(F::mul(a.zz, b.zz), PP);
         F ZZZ3 = F::mul(F::mul(a.zzz, b.zzz), PPP);
@@ -125,6 +126,9 @@ struct XYZZ {
     // out-of-line forms for kernels that chain many full additions (bucket reduction)
     __device__ __noinline__ static XYZZ add_ni(XYZZ a, XYZZ b) { return add(a, b); }
     __device__ __noinline__ static XYZZ dbl_ni(XYZZ a) { return dbl(a); }
+
+    // canonical representation of every coordinate (device values are relaxed, see field.hpp)
+    MSM_HD static XYZZ canon(const XYZZ& p) { return {F::canon(p.x), F::canon(p.y), F::canon(p.zz), F::canon(p.zzz)}; }
 
     MSM_HD static XYZZ neg(const XYZZ& p) { return {p.x, F::neg(p.y), p.zz, p.zzz}; }
 

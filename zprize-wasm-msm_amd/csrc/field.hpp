@@ -9,6 +9,11 @@
 // R = 2^(32*N), every result fully reduced to [0, q).  The byte image of an element is therefore
 // identical to the reference's linear-memory image.
 //
+// On the DEVICE values are kept "relaxed" in [0, 2q) between operations (see tools/gen_fp_asm.py): the
+// Montgomery product needs no final subtraction because R > 4q for both moduli, add/sub correct by 2q,
+// and canon() restores the reference's [0, q) representation wherever a value leaves the engine.
+// The HOST build of the same templates stays canonical throughout.
+//
 // Device multiplier: product-scanning Montgomery on 32-bit limbs.  v_mad_u64_u32 issues at full
 // rate on gfx950 (profiles/r01_valu_rates_microbench.txt), so one instruction does a 32x32
 // multiply and a 64-bit accumulate; its carry-out is folded into a third accumulator word with
@@ -18,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include "params_gen.hpp"
+#include "fp_asm_gen.hpp"
 
 #define MSM_HD __host__ __device__ __forceinline__
 #define MSM_D __device__ __forceinline__
@@ -71,34 +77,42 @@ struct Fp {
         for (int i = 0; i < N; ++i) r.v[i] = P::ONE[i];
         return r;
     }
-    MSM_HD bool is_zero() const {
+    // all limbs zero (the only representation of 0 on the host; one of two on the device)
+    MSM_HD bool is_zero_exact() const {
         uint32_t o = 0;
 #pragma unroll
         for (int i = 0; i < N; ++i) o |= v[i];
         return o == 0;
     }
-    MSM_HD bool is_one() const {
-        uint32_t o = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // relaxed: 0 is represented by 0 or by q
+    MSM_D bool is_zero() const {
+        uint32_t o = 0, oq = 0;
 #pragma unroll
+        for (int i = 0; i < N; ++i) {
+            o |= v[i];
+            oq |= v[i] ^ P::Q[i];
+        }
+        return o == 0 || oq == 0;
+    }
+    MSM_D static bool eq(const Fp& a, const Fp& b) { return sub(a, b).is_zero(); }
+    MSM_D bool is_one() const { return eq(*this, one()); }
+#else
+    bool is_zero() const { return is_zero_exact(); }
+    bool is_one() const {
+        uint32_t o = 0;
         for (int i = 0; i < N; ++i) o |= v[i] ^ P::ONE[i];
         return o == 0;
     }
-    MSM_HD static bool eq(const Fp& a, const Fp& b) {
+    static bool eq(const Fp& a, const Fp& b) {
         uint32_t o = 0;
-#pragma unroll
         for (int i = 0; i < N; ++i) o |= a.v[i] ^ b.v[i];
         return o == 0;
     }
+#endif
 
     // r = a - q if a >= q else a   (a < 2q, carry = bit 32N of a)
     MSM_HD static Fp reduce_once(const Fp& a, uint32_t carry) {
-#if 0 && defined(__HIP_DEVICE_COMPILE__)
-        // a < 2q < 2^(32N) for both supported moduli, so bit 32N (carry) is never set
-        (void)carry;
-        Fp r = a;
-        FpAsm<P>::reduce(r.v);
-        return r;
-#else
         Fp d;
         uint64_t br = 0;
 #pragma unroll
@@ -112,16 +126,33 @@ struct Fp {
 #pragma unroll
         for (int i = 0; i < N; ++i) r.v[i] = use_d ? d.v[i] : a.v[i];
         return r;
-#endif
     }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+    // r_i = (lane in mask) ? d_i : r_i
+    MSM_D static Fp select(Fp r, const Fp& d, uint64_t mask) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) asm("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r.v[i]) : "v"(d.v[i]), "s"(mask));
+        return r;
+    }
+    // relaxed [0, 2q) -> canonical [0, q)
+    MSM_D static Fp canon(const Fp& a) {
+        Fp d = a;
+        uint64_t ge = FpAsm<P>::add_minus_q(d.v);
+        return select(a, d, ge);
+    }
+#else
+    static Fp canon(const Fp& a) { return a; }
+#endif
 
     // build_f1m.js:71-89
     MSM_HD static Fp add(const Fp& a, const Fp& b) {
-#if 0 && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         Fp r;
-        (void)FpAsm<P>::add_raw(r.v, a.v, b.v);   // a + b < 2q < 2^(32N): no carry out
-        FpAsm<P>::reduce(r.v);
-        return r;
+        (void)FpAsm<P>::add_raw(r.v, a.v, b.v);          // < 4q < 2^(32N): no carry out
+        Fp d = r;
+        uint64_t ge = FpAsm<P>::add_minus_2q(d.v);       // d = r - 2q where r >= 2q
+        return select(r, d, ge);
 #else
         Fp s;
         uint64_t c = 0;
@@ -137,10 +168,10 @@ struct Fp {
     MSM_HD static Fp dbl(const Fp& a) { return add(a, a); }
     // build_f1m.js:91-105
     MSM_HD static Fp sub(const Fp& a, const Fp& b) {
-#if 0 && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         Fp r;
         uint64_t borrow = FpAsm<P>::sub_raw(r.v, a.v, b.v);
-        FpAsm<P>::add_q_masked(r.v, borrow);
+        (void)FpAsm<P>::add_2q_masked(r.v, borrow);      // (-2q, 2q) -> [0, 2q)
         return r;
 #else
         Fp d;
@@ -165,9 +196,9 @@ struct Fp {
     // build_f1m.js:107-117 (0 - x; neg(0) == 0)
     MSM_HD static Fp neg(const Fp& a) { return cneg(a, true); }
     MSM_HD static Fp cneg(const Fp& a, bool flag) {
-#if 0 && defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
         Fp r = a;
-        FpAsm<P>::rsub_q_masked(r.v, __ballot(flag && !a.is_zero()));   // q - a on the flagged lanes; -0 = 0
+        FpAsm<P>::rsub_2q_masked(r.v, __ballot(flag && !a.is_zero_exact()));   // 2q - a on the flagged lanes; -0 = 0
         return r;
 #else
         Fp n = sub(zero(), a);
@@ -205,7 +236,11 @@ struct Fp {
             lo = (lo >> 32) | ((uint64_t)hi << 32);
             hi = 0;
         }
+#if defined(__HIP_DEVICE_COMPILE__)
+        return r;   // relaxed inputs (< 2q) give t < 2q < 2^(32N); canonicalised only at the engine's outputs
+#else
         return reduce_once(r, (uint32_t)lo);
+#endif
     }
     // build_f1m.js:779-1076 -- square: off-diagonal products computed once and doubled.
     MSM_HD static Fp sqr_inl(const Fp& a) {
@@ -246,7 +281,11 @@ struct Fp {
             lo = (lo >> 32) | ((uint64_t)hi << 32);
             hi = 0;
         }
+        #if defined(__HIP_DEVICE_COMPILE__)
+        return r;
+#else
         return reduce_once(r, (uint32_t)lo);
+#endif
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -307,6 +346,7 @@ struct Fp2T {
     MSM_HD static Fp2T dbl(const Fp2T& a) { return add(a, a); }
     MSM_HD static Fp2T sub(const Fp2T& a, const Fp2T& b) { return {B::sub(a.c0, b.c0), B::sub(a.c1, b.c1)}; }
     MSM_HD static Fp2T neg(const Fp2T& a) { return {B::neg(a.c0), B::neg(a.c1)}; }
+    MSM_HD static Fp2T canon(const Fp2T& a) { return {B::canon(a.c0), B::canon(a.c1)}; }
     MSM_HD static Fp2T cneg(const Fp2T& a, bool f) { return {B::cneg(a.c0, f), B::cneg(a.c1, f)}; }
     // build_f2m.js:152-188 (Karatsuba, 3 base multiplications)
     MSM_HD static Fp2T mul(const Fp2T& a, const Fp2T& b) {

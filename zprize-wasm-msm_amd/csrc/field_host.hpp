@@ -87,6 +87,7 @@ struct FpH {
         return r;
     }
     static FpH neg(const FpH& a) { return sub(zero(), a); }
+    static FpH canon(const FpH& a) { return a; }
     static FpH cneg(const FpH& a, bool f) { return f ? neg(a) : a; }
     static FpH mul(const FpH& a, const FpH& b) {
         uint64_t t[N + 2];

@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __res
             a.x = F::mul(p.x, zi2);
             a.y = F::mul(p.y, F::mul(zi2, zi));
         }
-        store16(aff + (size_t)i * sizeof(Affine<F>), a);
+        store16(aff + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
     }
 }
 
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed
         acc = XYZZ<F>::dbl(acc);
         if ((k[bit >> 6] >> (bit & 63)) & 1ull) XYZZ<F>::madd(acc, gen.x, gen.y);
     }
-    Affine<F> a = XYZZ<F>::to_affine(acc);
+    Affine<F> a = Affine<F>::canon(XYZZ<F>::to_affine(acc));
     store16(out + (size_t)i * sizeof(Affine<F>), a);
 }
 
