@@ -78,6 +78,16 @@ int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
                            const void *scalars, uint32_t scalar_size, uint32_t n, uint32_t start_bit,
                            uint32_t chunk_size, uint8_t *out);
 
+/* ---- pipelined form ------------------------------------------------------------------------------ */
+/* msm_amd_multiexp_async queues the MSM and returns a ticket; msm_amd_wait blocks until it is done and
+ * writes the result.  Up to TWO tickets may be outstanding per context: the engine then overlaps the bucket
+ * reduction of the older call with the sort and bucket accumulation of the newer one (two HIP streams,
+ * double-buffered scratch).  Inputs must stay valid and unchanged until the ticket has been waited for.
+ * msm_amd_multiexp(...) == msm_amd_multiexp_async(...) + msm_amd_wait(...).                               */
+int msm_amd_multiexp_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
+                           const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);
+int msm_amd_wait(msm_amd_ctx *ctx, uint64_t ticket, uint8_t *out);
+
 /* ---- multi-GPU: one shard of the Pippenger windows -------------------------------------------- */
 /* Computes the contribution of windows {w : w % nshards == shard} (already weighted by 2^(c*w)),
  * written as an (un-normalised) Jacobian point.  Summing the nshards partials gives the MSM.      */

@@ -145,6 +145,39 @@ def test_long_buckets_are_segmented(eng, orc, curve, group):
         assert _fn(C, group, True)(b2, same, 32, m) == exp3
 
 
+def test_async_pipeline_two_in_flight(eng, orc):
+    """msm_amd_multiexp_async / msm_amd_wait: two calls in flight, different curves and sizes, results
+    collected out of submission order; a third submission is refused until a ticket is collected."""
+    import msm_amd
+    cases = []
+    for curve, group, n in (("bls12381", 1, 4000), ("bn128", 1, 700), ("bls12381", 2, 300), ("bls12381", 1, 0)):
+        bases, scalars = gu.random_case(curve, group, f"gpu:async:{curve}:{group}:{n}", n) if n else (b"", b"")
+        O = orc.Oracle(curve, group)
+        cases.append((curve, group, n, bases, scalars, O.normalize(O.multiexp_affine(bases, scalars, 32, n))))
+    t0 = eng.curve(cases[0][0]).multiexp_async(cases[0][1], cases[0][3], cases[0][4], 32, cases[0][2])
+    t1 = eng.curve(cases[1][0]).multiexp_async(cases[1][1], cases[1][3], cases[1][4], 32, cases[1][2])
+    with pytest.raises(msm_amd.MsmAmdError):
+        eng.curve("bls12381").multiexp_async(1, cases[0][3], cases[0][4], 32, cases[0][2])
+    assert t1.wait() == cases[1][5]
+    t2 = eng.curve(cases[2][0]).multiexp_async(cases[2][1], cases[2][3], cases[2][4], 32, cases[2][2])
+    assert t0.wait() == cases[0][5]
+    t3 = eng.curve(cases[3][0]).multiexp_async(cases[3][1], cases[3][3], cases[3][4], 32, cases[3][2])
+    assert t2.wait() == cases[2][5]
+    assert t3.wait() == cases[3][5]
+    with pytest.raises(msm_amd.MsmAmdError):
+        t3.wait()                                   # already collected
+    # steady-state pipeline on one input: every result identical
+    outs = []
+    prev = None
+    for _ in range(6):
+        cur = eng.curve(cases[0][0]).multiexp_async(cases[0][1], cases[0][3], cases[0][4], 32, cases[0][2])
+        if prev is not None:
+            outs.append(prev.wait())
+        prev = cur
+    outs.append(prev.wait())
+    assert all(o == cases[0][5] for o in outs)
+
+
 def test_error_codes(eng):
     import msm_amd
     C = eng.curve("bls12381")

@@ -484,19 +484,38 @@ struct DevBuf {
 
 using namespace msm;
 
+// One in-flight MSM: its scratch buffers, events and what the host needs to finish it.  A context owns
+// two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
+// the sort + accumulation of the next call (throughput-bound, stream A).
+struct Slot {
+    DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
+    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
+    void* h_partials = nullptr;   // pinned
+    size_t h_partials_cap = 0;
+    hipEvent_t ev[9] = {};        // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency)
+    bool pending = false;
+    bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
+    uint64_t ticket = 0;
+    Geom g{};
+    uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
+    bool raw_out = false;
+    int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
+    DevBuf* bufs[20] = {&d_dig, &d_tmp, &d_M, &d_Mscan, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+                        &d_affine, &d_count, &d_offset, &d_cursor, &d_order, &d_bins, &d_tiles, &d_sorted, &d_buckets, &d_partials};
+};
+
 struct msm_amd_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipStream_t stream = nullptr;     // A: transfers, sort, accumulation
+    hipStream_t stream_b = nullptr;   // B: bucket reduction, partials to host
+    Slot slots[2];
+    uint32_t next_slot = 0;
+    uint64_t next_ticket = 1;
     std::string err;
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
-    DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
-    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
-    void* h_partials = nullptr;   // pinned
-    size_t h_partials_cap = 0;
     float timings[8] = {};
     uint32_t geometry[6] = {};
 };
@@ -589,12 +608,17 @@ struct RunArgs {
 };
 
 template <class F>
-static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
+static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out);
+
+template <class F>
+static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     using X = XYZZ<F>;
     const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);
-    for (float& t : ctx->timings) t = 0.f;
+    sl->trivial = false;
+    sl->raw_out = a.raw_out;
+    sl->finish = &finish_msm<F>;
     if (a.n == 0 || a.nbits == 0) {
-        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
+        sl->trivial = true;
         return 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -614,12 +638,12 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         d_bases = (const uint8_t*)a.bases;
         d_scalars = (const uint8_t*)a.scalars;
     } else {
-        if (int rc = ensure(ctx, ctx->d_bases, base_bytes)) return rc;
-        if (int rc = ensure(ctx, ctx->d_scalars, scalar_bytes + 8)) return rc;
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_bases.p, a.bases, base_bytes, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
-        d_bases = (const uint8_t*)ctx->d_bases.p;
-        d_scalars = (const uint8_t*)ctx->d_scalars.p;
+        if (int rc = ensure(ctx, sl->d_bases, base_bytes)) return rc;
+        if (int rc = ensure(ctx, sl->d_scalars, scalar_bytes + 8)) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(sl->d_bases.p, a.bases, base_bytes, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(sl->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
+        d_bases = (const uint8_t*)sl->d_bases.p;
+        d_scalars = (const uint8_t*)sl->d_scalars.p;
     }
 
     Geom g;
@@ -640,39 +664,40 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     ctx->geometry[2] = g.half;
     ctx->geometry[3] = g.Wl;
     ctx->geometry[4] = ctx->geometry[5] = 0;
+    sl->g = g;
     if (g.Wl == 0) {
-        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
+        sl->trivial = true;
         return 0;
     }
     const uint32_t NB = g.Wl * g.half;
     const bool fast = (a.scalar_size % 4 == 0) && (((uintptr_t)d_scalars & 3) == 0);
 
-    HIPCHK(ctx, hipEventRecord(ctx->ev[0], st));
+    HIPCHK(ctx, hipEventRecord(sl->ev[0], st));
     // ---- Jacobian bases -> affine
     if (jac) {
-        if (int rc = ensure(ctx, ctx->d_affine, (size_t)a.n * ASZ)) return rc;
+        if (int rc = ensure(ctx, sl->d_affine, (size_t)a.n * ASZ)) return rc;
         uint32_t lanes = (a.n + 7) / 8;
-        k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)ctx->d_affine.p);
-        d_bases = (const uint8_t*)ctx->d_affine.p;
+        k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_affine.p);
+        d_bases = (const uint8_t*)sl->d_affine.p;
     }
-    HIPCHK(ctx, hipEventRecord(ctx->ev[1], st));
+    HIPCHK(ctx, hipEventRecord(sl->ev[1], st));
 
     const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
-    if (int rc = ensure(ctx, ctx->d_count, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_offset, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_cursor, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_order, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_bins, ORDER_BINS * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_tiles, (size_t)ntiles * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_buckets, (size_t)NB * XSZ)) return rc;
-    uint32_t* count = (uint32_t*)ctx->d_count.p;
-    uint32_t* offset = (uint32_t*)ctx->d_offset.p;
-    uint32_t* cursor = (uint32_t*)ctx->d_cursor.p;
-    uint32_t* order = (uint32_t*)ctx->d_order.p;
-    uint32_t* bins = (uint32_t*)ctx->d_bins.p;
-    uint32_t* tiles = (uint32_t*)ctx->d_tiles.p;
-    uint32_t* sorted = (uint32_t*)ctx->d_sorted.p;
+    if (int rc = ensure(ctx, sl->d_count, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_cursor, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_bins, ORDER_BINS * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * XSZ)) return rc;
+    uint32_t* count = (uint32_t*)sl->d_count.p;
+    uint32_t* offset = (uint32_t*)sl->d_offset.p;
+    uint32_t* cursor = (uint32_t*)sl->d_cursor.p;
+    uint32_t* order = (uint32_t*)sl->d_order.p;
+    uint32_t* bins = (uint32_t*)sl->d_bins.p;
+    uint32_t* tiles = (uint32_t*)sl->d_tiles.p;
+    uint32_t* sorted = (uint32_t*)sl->d_sorted.p;
 
     const uint32_t nblk = (a.n + 255) / 256;
     const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
@@ -682,7 +707,7 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
         if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
         else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. scan + order
         k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
         k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
@@ -690,11 +715,11 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. scatter
         if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
         else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     } else {
         // ---- 1. digit codes + coarse histogram
         const uint32_t fine_bits = std::min(8u, g.c - 1);
@@ -702,51 +727,53 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         const uint32_t stile = (a.n + SORT_TILE - 1) / SORT_TILE;
         const size_t NM = (size_t)g.Wl * cb * stile;                   // count matrix entries (+1 for the total)
         const uint32_t mtiles = (uint32_t)((NM + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        if (int rc = ensure(ctx, ctx->d_dig, (size_t)g.Wl * a.n * 2)) return rc;
-        if (int rc = ensure(ctx, ctx->d_tmp, (size_t)g.Wl * a.n * 8)) return rc;
-        if (int rc = ensure(ctx, ctx->d_M, (NM + 1) * 4)) return rc;
-        if (int rc = ensure(ctx, ctx->d_Mscan, (NM + 1) * 4 * 2)) return rc;
-        if (int rc = ensure(ctx, ctx->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
-        tiles = (uint32_t*)ctx->d_tiles.p;
-        uint16_t* dig = (uint16_t*)ctx->d_dig.p;
-        uint64_t* tmp = (uint64_t*)ctx->d_tmp.p;
-        uint32_t* M = (uint32_t*)ctx->d_M.p;
-        uint32_t* Mscan = (uint32_t*)ctx->d_Mscan.p;
+        if (int rc = ensure(ctx, sl->d_dig, (size_t)g.Wl * a.n * 2)) return rc;
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * a.n * 8)) return rc;
+        if (int rc = ensure(ctx, sl->d_M, (NM + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_Mscan, (NM + 1) * 4 * 2)) return rc;
+        if (int rc = ensure(ctx, sl->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
+        tiles = (uint32_t*)sl->d_tiles.p;
+        uint16_t* dig = (uint16_t*)sl->d_dig.p;
+        uint64_t* tmp = (uint64_t*)sl->d_tmp.p;
+        uint32_t* M = (uint32_t*)sl->d_M.p;
+        uint32_t* Mscan = (uint32_t*)sl->d_Mscan.p;
         uint32_t* Mdummy = Mscan + (NM + 1);
         if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
         k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, M);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[2], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. scan of the count matrix
         k_scan_tile_sums<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles);
         k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, mtiles);
         k_scan_apply<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles, Mscan, Mdummy);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[3], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
         k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, Mscan, tmp);
         k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
-        HIPCHK(ctx, hipEventRecord(ctx->ev[4], st));
+        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
     // ---- 4. accumulate
     using FK = typename KernelField<F>::type;
     // segment length: >= 4x the mean bucket population (random inputs never split); long buckets are cut
     uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(128u, 4u * ((a.n + g.half - 1) / g.half));
     const size_t max_segs = (size_t)g.Wl * a.n / seg + 1;
-    if (int rc = ensure(ctx, ctx->d_tailctl, sizeof(uint32_t) * 4)) return rc;
-    if (int rc = ensure(ctx, ctx->d_work, max_segs * 8)) return rc;
-    if (int rc = ensure(ctx, ctx->d_biglist, max_segs * 16)) return rc;
-    if (int rc = ensure(ctx, ctx->d_segout, max_segs * XSZ)) return rc;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_tailctl.p, 0, 16, st));
+    if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
+    if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
+    if (int rc = ensure(ctx, sl->d_segout, max_segs * XSZ)) return rc;
+    HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
     uint32_t tail_block = 256;
     while ((size_t)tail_block * XSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
-    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)ctx->d_buckets.p, seg, ctx->d_tailctl.p, ctx->d_work.p,
-                          ctx->d_biglist.p, (uint8_t*)ctx->d_segout.p, tail_block);
-    HIPCHK(ctx, hipEventRecord(ctx->ev[5], st));
-    // ---- 5. reduce
+    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)sl->d_buckets.p, seg, sl->d_tailctl.p, sl->d_work.p,
+                          sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
+    HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
+    // ---- 5. reduce (stream B: overlaps the next call's sort + accumulation on stream A)
+    hipStream_t sb = ctx->stream_b;
+    HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[5], 0));
     uint32_t L = ctx->force_L ? ctx->force_L : std::max(1u, g.half / 4096u);
     uint32_t lanes_per_window = (g.half + L - 1) / L;
     uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
@@ -754,25 +781,49 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     while ((size_t)rblock * XSZ > 64 * 1024 && rblock > 64) rblock /= 2;
     uint32_t wgs_per_window = (lanes_per_window + rblock - 1) / rblock;
     uint32_t nparts = g.Wl * wgs_per_window;
-    if (int rc = ensure(ctx, ctx->d_partials, (size_t)nparts * XSZ)) return rc;
-    if (ctx->h_partials_cap < (size_t)nparts * XSZ + 16) {
-        if (ctx->h_partials) HIPCHK(ctx, hipHostFree(ctx->h_partials));
-        ctx->h_partials = nullptr;
-        ctx->h_partials_cap = 0;
-        HIPCHK(ctx, hipHostMalloc(&ctx->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
-        ctx->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
+    if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ)) return rc;
+    if (sl->h_partials_cap < (size_t)nparts * XSZ + 16) {
+        if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
+        sl->h_partials = nullptr;
+        sl->h_partials_cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&sl->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
+        sl->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
     }
-    launch_bucket_reduce<FK>(st, nparts, rblock, (const uint8_t*)ctx->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
-                             (uint8_t*)ctx->d_partials.p);
-    HIPCHK(ctx, hipEventRecord(ctx->ev[6], st));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_partials, ctx->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, st));
+    launch_bucket_reduce<FK>(sb, nparts, rblock, (const uint8_t*)sl->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
+                             (uint8_t*)sl->d_partials.p);
+    HIPCHK(ctx, hipEventRecord(sl->ev[6], sb));
+    HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, sb));
     // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
-    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctx->h_partials) + (size_t)nparts * XSZ);
-    HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipEventRecord(ctx->ev[7], st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
+    HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
+    HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
+    HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
+    sl->wgs_per_window = wgs_per_window;
+    sl->nparts = nparts;
+    sl->NB = NB;
     HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
+    using X = XYZZ<F>;
+    const size_t XSZ = sizeof(X);
+    for (float& t : ctx->timings) t = 0.f;
+    const Geom& g = sl->g;
+    ctx->geometry[0] = g.c;
+    ctx->geometry[1] = g.W;
+    ctx->geometry[2] = g.half;
+    ctx->geometry[3] = g.Wl;
+    ctx->geometry[4] = ctx->geometry[5] = 0;
+    if (sl->trivial) {
+        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
+        return 0;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(sl->ev[7]));
+    const uint32_t wgs_per_window = sl->wgs_per_window, nparts = sl->nparts;
+    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
     {
         uint64_t entries = (uint64_t)h_tail[0] + h_tail[1];
         ctx->geometry[4] = (uint32_t)entries;
@@ -784,7 +835,7 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
     using HF = typename HostOf<F>::type;
     using HX = XYZZ<HF>;
     static_assert(sizeof(HX) == sizeof(X), "host twin has the same byte image");
-    const HX* parts = reinterpret_cast<const HX*>(ctx->h_partials);
+    const HX* parts = reinterpret_cast<const HX*>(sl->h_partials);
     HX total = HX::inf();
     int prev_w = -1;   // global index of the window most recently folded in
     for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
@@ -797,25 +848,24 @@ static int run_msm(msm_amd_ctx* ctx, const RunArgs& a, uint8_t* out) {
         prev_w = wglob;
     }
     for (int k = 0; k < prev_w * (int)g.c; ++k) total = HX::dbl(total);
-    if (a.raw_out) host_store_jacobian_raw(total, out);
+    if (sl->raw_out) host_store_jacobian_raw(total, out);
     else host_store_jacobian_normalised(total, out);
     auto t1 = std::chrono::steady_clock::now();
 
     float ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[7]); ctx->timings[0] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[1], ctx->ev[2]); ctx->timings[1] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); ctx->timings[2] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4]); ctx->timings[3] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]); ctx->timings[4] = ms;
-    (void)hipEventElapsedTime(&ms, ctx->ev[5], ctx->ev[6]); ctx->timings[5] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[7]); ctx->timings[0] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[1], sl->ev[2]); ctx->timings[1] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[2], sl->ev[3]); ctx->timings[2] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[3], sl->ev[4]); ctx->timings[3] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[4], sl->ev[5]); ctx->timings[4] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[5], sl->ev[6]); ctx->timings[5] = ms;
     ctx->timings[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    (void)hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); ctx->timings[7] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]); ctx->timings[7] = ms;
     return 0;
 }
 
-static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
-    if (!ctx) return MSM_AMD_EINVAL;
-    if (!out || (a.n && (!a.bases || !a.scalars))) {
+static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
+    if (a.n && (!a.bases || !a.scalars)) {
         ctx->err = "null pointer";
         return MSM_AMD_EINVAL;
     }
@@ -827,12 +877,63 @@ static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, ui
         ctx->err = "bad shard";
         return MSM_AMD_EINVAL;
     }
-    if (curve == MSM_AMD_BLS12381 && group == 1) return run_msm<Fp<Bls12381Fp>>(ctx, a, out);
-    if (curve == MSM_AMD_BLS12381 && group == 2) return run_msm<Fp2<Bls12381Fp>>(ctx, a, out);
-    if (curve == MSM_AMD_BN128 && group == 1) return run_msm<Fp<Bn254Fp>>(ctx, a, out);
-    if (curve == MSM_AMD_BN128 && group == 2) return run_msm<Fp2<Bn254Fp>>(ctx, a, out);
-    ctx->err = "unknown curve/group";
+    return 0;
+}
+
+// Queue one MSM on the next slot; the caller collects it with finish_ticket().
+static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint64_t* ticket) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (int rc = check_args(ctx, a)) return rc;
+    Slot* sl = &ctx->slots[ctx->next_slot];
+    if (sl->pending) sl = &ctx->slots[ctx->next_slot ^ 1u];   // tickets may be collected in any order
+    if (sl->pending) {
+        ctx->err = "two calls are already in flight on this context: wait for the older ticket first";
+        return MSM_AMD_EINVAL;
+    }
+    int rc;
+    if (curve == MSM_AMD_BLS12381 && group == 1) rc = submit_msm<Fp<Bls12381Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BLS12381 && group == 2) rc = submit_msm<Fp2<Bls12381Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BN128 && group == 1) rc = submit_msm<Fp<Bn254Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BN128 && group == 2) rc = submit_msm<Fp2<Bn254Fp>>(ctx, sl, a);
+    else {
+        ctx->err = "unknown curve/group";
+        return MSM_AMD_EINVAL;
+    }
+    if (rc) {
+        // leave the streams clean so the context stays usable
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream_b);
+        return rc;
+    }
+    sl->pending = true;
+    sl->ticket = ctx->next_ticket++;
+    *ticket = sl->ticket;
+    ctx->next_slot = (uint32_t)(sl - ctx->slots) ^ 1u;
+    return 0;
+}
+
+static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
+    if (!ctx || !out) return MSM_AMD_EINVAL;
+    for (Slot& sl : ctx->slots) {
+        if (sl.pending && sl.ticket == ticket) {
+            int rc = sl.finish(ctx, &sl, out);
+            sl.pending = false;
+            return rc;
+        }
+    }
+    ctx->err = "unknown or already collected ticket";
     return MSM_AMD_EINVAL;
+}
+
+static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (!out) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    uint64_t t = 0;
+    if (int rc = submit(ctx, curve, group, a, &t)) return rc;
+    return finish_ticket(ctx, t, out);
 }
 
 template <class F>
@@ -885,15 +986,17 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return MSM_AMD_EHIP;
     }
-    for (auto& e : ctx->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete ctx;
-            return MSM_AMD_EHIP;
-        }
+    for (Slot& sl : ctx->slots)
+        for (auto& e : sl.ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                delete ctx;
+                return MSM_AMD_EHIP;
+            }
     *out_ctx = ctx;
     return MSM_AMD_OK;
 }
@@ -902,13 +1005,16 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->d_tailctl, &ctx->d_work, &ctx->d_biglist, &ctx->d_segout, &ctx->d_dig, &ctx->d_tmp, &ctx->d_M, &ctx->d_Mscan, &ctx->d_bases, &ctx->d_scalars, &ctx->d_affine, &ctx->d_count, &ctx->d_offset, &ctx->d_cursor, &ctx->d_order, &ctx->d_bins,
-                      &ctx->d_tiles, &ctx->d_sorted, &ctx->d_buckets, &ctx->d_partials})
-        if (b->p) (void)hipFree(b->p);
-    if (ctx->h_partials) (void)hipHostFree(ctx->h_partials);
-    for (auto& e : ctx->ev)
-        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
+    for (Slot& sl : ctx->slots) {
+        for (DevBuf* b : sl.bufs)
+            if (b->p) (void)hipFree(b->p);
+        if (sl.h_partials) (void)hipHostFree(sl.h_partials);
+        for (auto& e : sl.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
     delete ctx;
 }
 
@@ -935,6 +1041,15 @@ int msm_amd_multiexp(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, con
     RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
     return dispatch(ctx, curve, group, a, out);
 }
+
+int msm_amd_multiexp_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
+                           uint32_t n, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
+    return submit(ctx, curve, group, a, ticket);
+}
+
+int msm_amd_wait(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) { return finish_ticket(ctx, ticket, out); }
 
 int msm_amd_multiexp_chunk(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
                            uint32_t scalar_size, uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {

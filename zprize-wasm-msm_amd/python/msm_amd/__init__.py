@@ -54,6 +54,8 @@ def load_library(path=None):
     L.msm_amd_set_window_bits.argtypes = [vp, u32]
     L.msm_amd_set_option.argtypes = [vp, c.c_char_p, u32]
     L.msm_amd_multiexp.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
+    L.msm_amd_multiexp_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, c.POINTER(c.c_uint64)]
+    L.msm_amd_wait.argtypes = [vp, c.c_uint64, u8p]
     L.msm_amd_multiexp_chunk.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_multiexp_shard.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_combine.argtypes = [c.c_int, c.c_int, vp, u32, u8p]
@@ -168,6 +170,19 @@ class Engine:
                 "entries": arr[4] | (arr[5] << 32)}
 
 
+class Ticket:
+    """Handle of a queued MSM (msm_amd_multiexp_async); wait() returns the normalised Jacobian bytes."""
+
+    def __init__(self, curve, group, value, keepalive):
+        self.curve, self.group, self.value, self._keep = curve, group, value, keepalive
+
+    def wait(self):
+        out = ctypes.create_string_buffer(self.curve.jacobian_bytes(self.group))
+        self.curve.eng._chk(self.curve.eng.L.msm_amd_wait(self.curve.eng.ctx, self.value, out))
+        self._keep = None
+        return out.raw
+
+
 class Curve:
     """Export-named view of one curve (the reference builds one WASM module per curve)."""
 
@@ -203,6 +218,17 @@ class Curve:
         self.eng._chk(self.eng.L.msm_amd_multiexp_chunk(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
                                                         start_bit, chunk_size, out))
         return out.raw
+
+    # --- pipelined form: up to two calls in flight per engine (reduction of one overlaps accumulation of the next)
+    def multiexp_async(self, group, bases, scalars, scalar_size, n, jacobian_bases=False):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        if dev_b != dev_s:
+            raise MsmAmdError("bases and scalars must both be host or both be device buffers")
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        t = ctypes.c_uint64()
+        self.eng._chk(self.eng.L.msm_amd_multiexp_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, ctypes.byref(t)))
+        return Ticket(self, group, t.value, (kb, ks))
 
     # --- the reference's export names -------------------------------------------------------
     def g1m_multiexp(self, bases, scalars, scalar_size, n): return self._multiexp(1, FLAG_JACOBIAN, bases, scalars, scalar_size, n)
