@@ -110,7 +110,14 @@ def main():
         for k, v in eng.timings().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
 
-    pipelined = world == 1 and not args.no_pipeline
+    pipelined = not args.no_pipeline
+
+    def finish(ticket):
+        out = ticket.wait()
+        if world == 1:
+            return out
+        # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, then the host adds them
+        return mdist.gather_and_combine(args.curve, g, out, device=dev)
     sync()
     t0 = time.perf_counter()
     if pipelined:
@@ -118,12 +125,15 @@ def main():
         # step i+1 (stream A); every step is waited for inside the timed region
         prev = None
         for _ in range(args.steps):
-            cur = C.multiexp_async(g, pts, d_scalars, 32, n)
+            if world == 1:
+                cur = C.multiexp_async(g, pts, d_scalars, 32, n)
+            else:
+                cur = C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world)
             if prev is not None:
-                result = prev.wait()
+                result = finish(prev)
                 collect()
             prev = cur
-        result = prev.wait()
+        result = finish(prev)
         collect()
     else:
         for _ in range(args.steps):

@@ -94,6 +94,10 @@ int msm_amd_wait(msm_amd_ctx *ctx, uint64_t ticket, uint8_t *out);
 int msm_amd_multiexp_shard(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
                            const void *scalars, uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards,
                            uint8_t *out_partial);
+/* pipelined form of the same (collect with msm_amd_wait; the ticket yields the un-normalised partial) */
+int msm_amd_multiexp_shard_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
+                                 const void *scalars, uint32_t scalar_size, uint32_t n, uint32_t shard,
+                                 uint32_t nshards, uint64_t *ticket);
 /* out = normalise(sum of `count` Jacobian partials) -- host only, no GPU needed */
 int msm_amd_combine(int curve, int group, const uint8_t *partials, uint32_t count, uint8_t *out);
 

@@ -20,6 +20,7 @@
 // one v_addc_co_u32.  The host build of the same templates uses portable 64-bit C.
 #pragma once
 #include <cstdint>
+#include <utility>
 #include <hip/hip_runtime.h>
 
 #include "params_gen.hpp"
@@ -289,8 +290,26 @@ struct Fp {
     }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-    __device__ __noinline__ static Fp mul_ni(Fp a, Fp b) { return mul_inl(a, b); }
-    __device__ __noinline__ static Fp sqr_ni(Fp a) { return sqr_inl(a); }
+    // Out-of-line bodies take their limbs as 2N (or N) scalar arguments so that both operands travel in
+    // VGPRs (a by-value struct argument beyond the first would be passed through scratch memory).
+    template <size_t>
+    using limb_t = uint32_t;
+    template <size_t... I>
+    __device__ __noinline__ static Fp mul_ni_(std::index_sequence<I...>, limb_t<I>... a, limb_t<I>... b) {
+        Fp x{{a...}}, y{{b...}};
+        return mul_inl(x, y);
+    }
+    template <size_t... I>
+    __device__ __noinline__ static Fp sqr_ni_(std::index_sequence<I...>, limb_t<I>... a) {
+        Fp x{{a...}};
+        return sqr_inl(x);
+    }
+    template <size_t... I>
+    MSM_D static Fp mul_ni_x(std::index_sequence<I...> q, const Fp& a, const Fp& b) { return mul_ni_(q, a.v[I]..., b.v[I]...); }
+    template <size_t... I>
+    MSM_D static Fp sqr_ni_x(std::index_sequence<I...> q, const Fp& a) { return sqr_ni_(q, a.v[I]...); }
+    MSM_D static Fp mul_ni(const Fp& a, const Fp& b) { return mul_ni_x(std::make_index_sequence<N>{}, a, b); }
+    MSM_D static Fp sqr_ni(const Fp& a) { return sqr_ni_x(std::make_index_sequence<N>{}, a); }
     MSM_D static Fp mul(const Fp& a, const Fp& b) {
         if constexpr (INL) return mul_inl(a, b);
         else return mul_ni(a, b);

@@ -587,10 +587,9 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
     if (forced) {
         c = forced;
     } else {
-        uint32_t lg = 0;
-        while ((1ull << lg) < n) ++lg;
-        c = lg > 4 ? lg - 4 : 1;
-        if (c > 16) c = 16;
+        // measured on MI355X (profiles/r01_sweep_window_bits.log): the bucket reduction costs ~1.1 ms whatever n is
+        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits.
+        c = n >= 4096 ? 16 : 8;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
@@ -774,7 +773,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // ---- 5. reduce (stream B: overlaps the next call's sort + accumulation on stream A)
     hipStream_t sb = ctx->stream_b;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[5], 0));
-    uint32_t L = ctx->force_L ? ctx->force_L : std::max(1u, g.half / 4096u);
+    // buckets per lane: 8 when every window is owned (throughput), fewer when a shard owns few windows (latency)
+    uint32_t L = ctx->force_L ? ctx->force_L : std::min(8u, std::max(1u, NB / 65536u));
     uint32_t lanes_per_window = (g.half + L - 1) / L;
     uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
     // LDS budget: rblock * XSZ must fit in 64 KB (default limit); shrink for wide fields
@@ -1046,6 +1046,13 @@ int msm_amd_multiexp_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
                            uint32_t n, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
     RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
+    return submit(ctx, curve, group, a, ticket);
+}
+
+int msm_amd_multiexp_shard_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                                 uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, shard, nshards, true};
     return submit(ctx, curve, group, a, ticket);
 }
 

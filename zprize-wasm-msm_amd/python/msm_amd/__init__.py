@@ -56,6 +56,7 @@ def load_library(path=None):
     L.msm_amd_multiexp.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
     L.msm_amd_multiexp_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_wait.argtypes = [vp, c.c_uint64, u8p]
+    L.msm_amd_multiexp_shard_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_multiexp_chunk.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_multiexp_shard.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_combine.argtypes = [c.c_int, c.c_int, vp, u32, u8p]
@@ -260,6 +261,15 @@ class Curve:
         self.eng._chk(self.eng.L.msm_amd_multiexp_shard(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
                                                         shard, nshards, out))
         return out.raw
+
+    def multiexp_shard_async(self, group, bases, scalars, scalar_size, n, shard, nshards, jacobian_bases=False):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        t = ctypes.c_uint64()
+        self.eng._chk(self.eng.L.msm_amd_multiexp_shard_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
+                                                              shard, nshards, ctypes.byref(t)))
+        return Ticket(self, group, t.value, (kb, ks))
 
     def gen_points(self, group, seed, n):
         buf = self.eng.alloc(max(16, n * self.affine_bytes(group)))
