@@ -154,6 +154,28 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t* __restrict__ scal
     }
 }
 
+// c == 16, 32-byte aligned scalars, whole scalar: the raw digits are the 16 half-words of the scalar (two 16-byte loads)
+__global__ void __launch_bounds__(256) k_digits_c16(const uint8_t* __restrict__ scalars, Geom g, uint16_t* __restrict__ dig) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= g.n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + (size_t)i * 2;
+    uint4 lo = sp[0], hi = sp[1];
+    uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t carry = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < 17; ++w) {
+        uint32_t raw = w < 16 ? ((wd[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) : 0u;
+        raw += carry;
+        bool negd = raw > 0x8000u;
+        uint32_t mag = negd ? 0x10000u - raw : raw;
+        carry = negd ? 1u : 0u;
+        if ((w % g.nshards) == g.shard) {
+            uint32_t code = mag == 0 ? DIGIT_ZERO : ((negd ? 0x8000u : 0u) | (mag - 1));
+            dig[(size_t)(w / g.nshards) * g.n + i] = (uint16_t)code;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(SORT_BLOCK) k_coarse_hist(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
                                                               uint32_t ntile, uint32_t* __restrict__ M) {
     __shared__ uint32_t h[COARSE_MAX];
@@ -241,41 +263,88 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_coarse_scatter(const uint16_t* _
 __global__ void __launch_bounds__(SORT_BLOCK) k_fine_sort(const uint64_t* __restrict__ tmp, const uint32_t* __restrict__ Mscan, uint32_t ntile,
                                                             uint32_t nbins_total, uint32_t fine_bits, uint32_t cb, uint32_t half,
                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ count, uint32_t* __restrict__ offset) {
-    __shared__ uint32_t h[256];
-    __shared__ uint32_t lofs[256];
-    const uint32_t bin = blockIdx.x;                       // = wl * cb + coarse bin
+    // One workgroup per (window, coarse bin).  Sweep 1: histogram of the fine key -> bucket count/offset.
+    // Sweep 2: the bin is walked in tiles of SORT_TILE entries; each tile is counting-sorted in LDS and
+    // every (tile, bucket) run is then stored by consecutive lanes, so the writes into `sorted` are
+    // coalesced runs instead of 4-byte scatters (which cost 6x write amplification, profiles/r01_pmc_*).
+    __shared__ uint32_t h[256];        // bucket populations of the whole bin
+    __shared__ uint32_t lofs[256];     // bucket start inside the bin, advanced tile by tile
+    __shared__ uint32_t th[256];       // tile: counts, then cursors
+    __shared__ uint32_t tstart[256];   // tile: start of each bucket inside the staged tile
+    __shared__ uint32_t delta[256];    // global position of staged slot s = delta[bucket] + s
+    __shared__ uint64_t stage[SORT_TILE];
+    const uint32_t bin = blockIdx.x;                          // = wl * cb + coarse bin
     const uint32_t start = Mscan[(size_t)bin * ntile];
-    const uint32_t end = Mscan[(size_t)(bin + 1) * ntile];   // the scan carries one extra element = total
+    const uint32_t end = Mscan[(size_t)(bin + 1) * ntile];    // the scan carries one extra element = total
     const uint32_t nf = 1u << fine_bits;
-    h[threadIdx.x] = 0;
+    const uint32_t t = threadIdx.x;
+    h[t] = 0;
     __syncthreads();
-    for (uint32_t p = start + threadIdx.x; p < end; p += SORT_BLOCK) atomicAdd(&h[(uint32_t)(tmp[p] >> 32) & 0xFFu], 1u);
+    for (uint32_t p = start + t; p < end; p += SORT_BLOCK) atomicAdd(&h[(uint32_t)(tmp[p] >> 32) & 0xFFu], 1u);
     __syncthreads();
-    uint32_t v = h[threadIdx.x];
-    lofs[threadIdx.x] = v;
+    uint32_t v = h[t];
+    lofs[t] = v;
     __syncthreads();
     for (int dd = 1; dd < 256; dd <<= 1) {
-        uint32_t t = (int)threadIdx.x >= dd ? lofs[threadIdx.x - dd] : 0;
+        uint32_t x = (int)t >= dd ? lofs[t - dd] : 0;
         __syncthreads();
-        lofs[threadIdx.x] += t;
+        lofs[t] += x;
         __syncthreads();
     }
-    uint32_t excl = lofs[threadIdx.x] - v;
+    uint32_t excl = lofs[t] - v;
     __syncthreads();
-    lofs[threadIdx.x] = excl;
-    h[threadIdx.x] = 0;
-    if (threadIdx.x < nf) {
+    lofs[t] = excl;
+    if (t < nf) {
         uint32_t wl = bin / cb, cbin = bin % cb;
-        uint32_t gb = wl * half + (cbin << fine_bits) + threadIdx.x;
+        uint32_t gb = wl * half + (cbin << fine_bits) + t;
         count[gb] = v;
         offset[gb] = start + excl;
     }
     __syncthreads();
-    for (uint32_t p = start + threadIdx.x; p < end; p += SORT_BLOCK) {
-        uint64_t e = tmp[p];
-        uint32_t f = (uint32_t)(e >> 32) & 0xFFu;
-        uint32_t r = atomicAdd(&h[f], 1u);
-        sorted[start + lofs[f] + r] = (uint32_t)e;
+    for (uint32_t tb = start; tb < end; tb += SORT_TILE) {
+        const uint32_t tn = min((uint32_t)SORT_TILE, end - tb);
+        th[t] = 0;
+        __syncthreads();
+        uint64_t e[SORT_ITEMS];
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; ++k) {
+            uint32_t s = k * SORT_BLOCK + t;
+            e[k] = s < tn ? tmp[tb + s] : ~0ull;
+            if (s < tn) atomicAdd(&th[(uint32_t)(e[k] >> 32) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        uint32_t c = th[t];
+        tstart[t] = c;
+        __syncthreads();
+        for (int dd = 1; dd < 256; dd <<= 1) {
+            uint32_t x = (int)t >= dd ? tstart[t - dd] : 0;
+            __syncthreads();
+            tstart[t] += x;
+            __syncthreads();
+        }
+        uint32_t ts = tstart[t] - c;
+        __syncthreads();
+        tstart[t] = ts;
+        delta[t] = start + lofs[t] - ts;   // mod 2^32
+        lofs[t] += c;                      // next tile of this bucket continues here
+        th[t] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT_ITEMS; ++k) {
+            uint32_t s = k * SORT_BLOCK + t;
+            if (s < tn) {
+                uint32_t f = (uint32_t)(e[k] >> 32) & 0xFFu;
+                uint32_t r = atomicAdd(&th[f], 1u);
+                stage[tstart[f] + r] = e[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = t; s < tn; s += SORT_BLOCK) {
+            uint64_t x = stage[s];
+            uint32_t f = (uint32_t)(x >> 32) & 0xFFu;
+            sorted[(uint32_t)(delta[f] + s)] = (uint32_t)x;
+        }
+        __syncthreads();
     }
     (void)nbins_total;
 }
@@ -737,7 +806,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         uint32_t* M = (uint32_t*)sl->d_M.p;
         uint32_t* Mscan = (uint32_t*)sl->d_Mscan.p;
         uint32_t* Mdummy = Mscan + (NM + 1);
-        if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        const bool c16 = g.c == 16 && a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && g.W == 17 && (((uintptr_t)d_scalars & 15) == 0);
+        if (c16) k_digits_c16<<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        else if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
         k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, M);
