@@ -68,15 +68,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share GPUs
+    # and the 144-byte partials travel through host memory); the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("MSM_BENCH_BACKEND", "nccl")
+    ngpu = torch.cuda.device_count()
+    gpu_index = local_rank if backend == "nccl" else local_rank % max(1, ngpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(gpu_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu_index))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    dev = torch.device("cuda", gpu_index)
     torch.cuda.set_device(dev)
+    xdev = dev if backend == "nccl" else torch.device("cpu")    # where the partials are exchanged
 
     n = 1 << args.logn
-    eng = msm_amd.Engine(local_rank)          # fails loudly without the HIP library / a GPU
+    eng = msm_amd.Engine(gpu_index)           # fails loudly without the HIP library / a GPU
     if args.window_bits:
         eng.set_window_bits(args.window_bits)
     C = eng.curve(args.curve)
@@ -93,7 +102,7 @@ def main():
         if world == 1:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
         # windows sharded over the ranks; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
-        return mdist.multiexp_sharded(C, g, pts, d_scalars, 32, n, device=dev)
+        return mdist.multiexp_sharded(C, g, pts, d_scalars, 32, n, device=xdev)
 
     def sync():
         torch.cuda.synchronize()
@@ -111,30 +120,34 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
 
     pipelined = not args.no_pipeline
+    # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
+    # windows are sharded the accumulation per rank shrinks but the reduction latency does not, so more are needed
+    depth = 1 if not pipelined else (2 if world <= 2 else 4)
+    eng.set_option("slots", max(depth, 1))
 
     def finish(ticket):
         out = ticket.wait()
         if world == 1:
             return out
         # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, then the host adds them
-        return mdist.gather_and_combine(args.curve, g, out, device=dev)
+        return mdist.gather_and_combine(args.curve, g, out, device=xdev)
     sync()
     t0 = time.perf_counter()
     if pipelined:
         # two steps in flight: the bucket reduction of step i (stream B) overlaps the sort + accumulation of
         # step i+1 (stream A); every step is waited for inside the timed region
-        prev = None
+        inflight = []
         for _ in range(args.steps):
             if world == 1:
-                cur = C.multiexp_async(g, pts, d_scalars, 32, n)
+                inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
             else:
-                cur = C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world)
-            if prev is not None:
-                result = finish(prev)
+                inflight.append(C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
+            if len(inflight) == depth:
+                result = finish(inflight.pop(0))
                 collect()
-            prev = cur
-        result = finish(prev)
-        collect()
+        while inflight:
+            result = finish(inflight.pop(0))
+            collect()
     else:
         for _ in range(args.steps):
             result = step()
@@ -142,7 +155,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     geom = eng.geometry()
@@ -176,7 +189,7 @@ def main():
             "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); inputs resident in HBM",
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
-                       "calls_in_flight": 2 if pipelined else 1,
+                       "calls_in_flight": depth,
                        "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
             "roofline": {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

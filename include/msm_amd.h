@@ -66,7 +66,7 @@ const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
 /* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
  * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
- * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition). */
+ * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 
 /* ---- generic entry points -------------------------------------------------------------------- */
@@ -80,9 +80,9 @@ int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
 
 /* ---- pipelined form ------------------------------------------------------------------------------ */
 /* msm_amd_multiexp_async queues the MSM and returns a ticket; msm_amd_wait blocks until it is done and
- * writes the result.  Up to TWO tickets may be outstanding per context: the engine then overlaps the bucket
- * reduction of the older call with the sort and bucket accumulation of the newer one (two HIP streams,
- * double-buffered scratch).  Inputs must stay valid and unchanged until the ticket has been waited for.
+ * writes the result.  Up to `slots` tickets (default 2, option "slots" 1..4) may be outstanding per context:
+ * the engine overlaps the bucket reductions of older calls (one HIP stream per slot) with the sort and bucket
+ * accumulation of the newest one (each slot has its own scratch buffers).  Inputs must stay valid and unchanged until the ticket has been waited for.
  * msm_amd_multiexp(...) == msm_amd_multiexp_async(...) + msm_amd_wait(...).                               */
 int msm_amd_multiexp_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
                            const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);

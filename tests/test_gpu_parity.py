@@ -176,6 +176,14 @@ def test_async_pipeline_two_in_flight(eng, orc):
         prev = cur
     outs.append(prev.wait())
     assert all(o == cases[0][5] for o in outs)
+    # four slots: four calls in flight, collected in reverse order
+    eng.set_option("slots", 4)
+    try:
+        ts = [eng.curve(c[0]).multiexp_async(c[1], c[3], c[4], 32, c[2]) for c in cases]
+        for tk, c in reversed(list(zip(ts, cases))):
+            assert tk.wait() == c[5]
+    finally:
+        eng.set_option("slots", 2)
 
 
 def test_error_codes(eng):

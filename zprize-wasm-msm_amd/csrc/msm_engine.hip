@@ -562,6 +562,7 @@ struct Slot {
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     hipEvent_t ev[9] = {};        // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency)
+    hipStream_t stream_b = nullptr;   // B: this slot's bucket reduction + partials to host
     bool pending = false;
     bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
     uint64_t ticket = 0;
@@ -576,8 +577,9 @@ struct Slot {
 struct msm_amd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     // A: transfers, sort, accumulation
-    hipStream_t stream_b = nullptr;   // B: bucket reduction, partials to host
-    Slot slots[2];
+    static constexpr uint32_t MAX_SLOTS = 4;
+    Slot slots[MAX_SLOTS];
+    uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..4)
     uint32_t next_slot = 0;
     uint64_t next_ticket = 1;
     std::string err;
@@ -842,7 +844,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
                           sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
     // ---- 5. reduce (stream B: overlaps the next call's sort + accumulation on stream A)
-    hipStream_t sb = ctx->stream_b;
+    hipStream_t sb = sl->stream_b;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[5], 0));
     // buckets per lane: 8 when every window is owned (throughput), fewer when a shard owns few windows (latency)
     uint32_t L = ctx->force_L ? ctx->force_L : std::min(8u, std::max(1u, NB / 65536u));
@@ -955,10 +957,16 @@ static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
 static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint64_t* ticket) {
     if (!ctx) return MSM_AMD_EINVAL;
     if (int rc = check_args(ctx, a)) return rc;
-    Slot* sl = &ctx->slots[ctx->next_slot];
-    if (sl->pending) sl = &ctx->slots[ctx->next_slot ^ 1u];   // tickets may be collected in any order
-    if (sl->pending) {
-        ctx->err = "two calls are already in flight on this context: wait for the older ticket first";
+    Slot* sl = nullptr;
+    for (uint32_t k = 0; k < ctx->nslots; ++k) {   // tickets may be collected in any order: take any free slot
+        Slot* cand = &ctx->slots[(ctx->next_slot + k) % ctx->nslots];
+        if (!cand->pending) {
+            sl = cand;
+            break;
+        }
+    }
+    if (!sl) {
+        ctx->err = "every slot of this context holds an uncollected call: wait for an older ticket first";
         return MSM_AMD_EINVAL;
     }
     int rc;
@@ -973,13 +981,13 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
     if (rc) {
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamSynchronize(ctx->stream_b);
+        (void)hipStreamSynchronize(sl->stream_b);
         return rc;
     }
     sl->pending = true;
     sl->ticket = ctx->next_ticket++;
     *ticket = sl->ticket;
-    ctx->next_slot = (uint32_t)(sl - ctx->slots) ^ 1u;
+    ctx->next_slot = ((uint32_t)(sl - ctx->slots) + 1u) % ctx->nslots;
     return 0;
 }
 
@@ -1057,17 +1065,21 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return MSM_AMD_EHIP;
     }
-    for (Slot& sl : ctx->slots)
+    for (Slot& sl : ctx->slots) {
+        if (hipStreamCreateWithFlags(&sl.stream_b, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return MSM_AMD_EHIP;
+        }
         for (auto& e : sl.ev)
             if (hipEventCreate(&e) != hipSuccess) {
                 delete ctx;
                 return MSM_AMD_EHIP;
             }
+    }
     *out_ctx = ctx;
     return MSM_AMD_OK;
 }
@@ -1076,8 +1088,11 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->stream_b) (void)hipStreamSynchronize(ctx->stream_b);
     for (Slot& sl : ctx->slots) {
+        if (sl.stream_b) {
+            (void)hipStreamSynchronize(sl.stream_b);
+            (void)hipStreamDestroy(sl.stream_b);
+        }
         for (DevBuf* b : sl.bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.h_partials) (void)hipHostFree(sl.h_partials);
@@ -1085,7 +1100,6 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
             if (e) (void)hipEventDestroy(e);
     }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
     delete ctx;
 }
 
@@ -1097,6 +1111,14 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
     if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
     if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
+    if (!strcmp(name, "slots")) {
+        if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 4]"; return MSM_AMD_EINVAL; }
+        for (Slot& sl : ctx->slots)
+            if (sl.pending) { ctx->err = "cannot change the slot count with calls in flight"; return MSM_AMD_EINVAL; }
+        ctx->nslots = value;
+        ctx->next_slot = 0;
+        return 0;
+    }
     ctx->err = "unknown option";
     return MSM_AMD_EINVAL;
 }
