@@ -186,6 +186,45 @@ def test_async_pipeline_two_in_flight(eng, orc):
         eng.set_option("slots", 2)
 
 
+def test_randomised_configurations(eng, orc):
+    """40 seeded random combinations of curve, n, scalar size, window bits, segment length, reduction fan-out and
+    entry point (full / chunk / shard), each against the oracle."""
+    import random
+    import msm_amd
+    rnd = random.Random(20261003)
+    try:
+        for it in range(40):
+            curve = rnd.choice(["bls12381", "bn128"])
+            group = 1 if rnd.random() < 0.75 else 2
+            n = rnd.choice([1, 2, 7, 33, 100, 257, 1000, 2500] if group == 1 else [1, 5, 64, 300])
+            ss = rnd.choice([32, 32, 32, 31, 16, 8, 3, 40, 64])
+            C = eng.curve(curve)
+            O = orc.Oracle(curve, group)
+            bases, _ = gu.random_case(curve, group, f"gpu:rand:{it}", n)
+            scalars = gu.stream(f"gpu:rand:{it}:s", n * ss)
+            eng.set_window_bits(rnd.choice([0, 0, 1, 3, 4, 7, 11, 16]))
+            eng.set_option("segment", rnd.choice([0, 0, 1, 2, 5, 64]))
+            eng.set_option("reduce_l", rnd.choice([0, 0, 1, 3, 16]))
+            mode = rnd.choice(["full", "full", "chunk", "shard"])
+            if mode == "full":
+                exp = O.normalize(O.multiexp_affine(bases, scalars, ss, n))
+                got = _fn(C, group, True)(bases, scalars, ss, n)
+            elif mode == "chunk":
+                start = rnd.randrange(0, ss * 8)
+                cs = rnd.randrange(1, 26)
+                exp = O.normalize(O.multiexp_chunk(bases, scalars, ss, n, start, cs))
+                got = _fn(C, group, True, True)(bases, scalars, ss, n, start, cs)
+            else:
+                k = rnd.choice([2, 3, 5])
+                exp = O.normalize(O.multiexp_affine(bases, scalars, ss, n))
+                got = msm_amd.combine(curve, group, b"".join(C.multiexp_shard(group, bases, scalars, ss, n, r, k) for r in range(k)))
+            assert got == gu.canon(curve, group, exp, O.zero()), (it, curve, group, n, ss, mode, eng.geometry())
+    finally:
+        eng.set_window_bits(0)
+        eng.set_option("segment", 0)
+        eng.set_option("reduce_l", 0)
+
+
 def test_error_codes(eng):
     import msm_amd
     C = eng.curve("bls12381")

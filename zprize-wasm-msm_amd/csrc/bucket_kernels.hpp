@@ -9,8 +9,8 @@ namespace msm {
 
 // ------------------------------------------------------------------------------------------
 // stage 4: bucket accumulation -- one lane per bucket.
-// A lane adds at most `seg` entries of its bucket (seg >= 4x the mean population, so random inputs
-// never exceed it).  A longer bucket -- adversarial scalars, e.g. all equal -- is cut into further
+// A lane adds at most `seg` entries of its bucket (seg = max(32, 2x the mean population): random inputs
+// practically never exceed it).  A longer bucket -- adversarial scalars, e.g. all equal -- is cut into further
 // segments that the lane appends to a work list; k_accumulate_tail sums those segments with one
 // lane each and k_combine_tail folds them back into the bucket.  With no long bucket the two tail
 // kernels find empty lists and return.

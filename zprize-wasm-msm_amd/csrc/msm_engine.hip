@@ -830,8 +830,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     // ---- 4. accumulate
     using FK = typename KernelField<F>::type;
-    // segment length: >= 4x the mean bucket population (random inputs never split); long buckets are cut
-    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(128u, 4u * ((a.n + g.half - 1) / g.half));
+    // segment length: 2x the mean bucket population, at least 32 (a Poisson bucket practically never exceeds it);
+    // longer buckets -- adversarial scalars, or the few buckets of a narrow top window when the scalar width is
+    // not a multiple of c -- are cut into segments, which bounds the longest dependent chain of additions
+    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, 2u * ((a.n + g.half - 1) / g.half));
     const size_t max_segs = (size_t)g.Wl * a.n / seg + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
