@@ -849,7 +849,11 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     hipStream_t sb = sl->stream_b;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[5], 0));
     // buckets per lane: 8 when every window is owned (throughput), fewer when a shard owns few windows (latency)
-    uint32_t L = ctx->force_L ? ctx->force_L : std::min(8u, std::max(1u, NB / 65536u));
+    // ... and 16 when another call is already in flight: its latency is hidden behind that call's accumulation,
+    // and fewer, longer lanes cost less SIMD time (profiles: 3.99 -> 3.91 ms per pipelined call at n = 2^20)
+    bool others_pending = false;
+    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
+    uint32_t L = ctx->force_L ? ctx->force_L : std::min(others_pending ? 16u : 8u, std::max(1u, NB / 65536u));
     uint32_t lanes_per_window = (g.half + L - 1) / L;
     uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
     // LDS budget: rblock * XSZ must fit in 64 KB (default limit); shrink for wide fields
@@ -946,6 +950,10 @@ static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
     }
     if (a.scalar_size < 1 || a.scalar_size > 64) {
         ctx->err = "scalar_size must be in [1, 64]";
+        return MSM_AMD_EINVAL;
+    }
+    if (a.n > (1u << 27)) {   // (pair, window) positions are 32-bit: 17 windows x n must stay below 2^32
+        ctx->err = "n must not exceed 2^27 per call (split larger inputs by points and add the results with msm_amd_combine)";
         return MSM_AMD_EINVAL;
     }
     if (a.nshards == 0 || a.shard >= a.nshards) {
