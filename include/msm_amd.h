@@ -128,6 +128,17 @@ int msm_amd_eq(int curve, int group, const uint8_t *jac_a, const uint8_t *jac_b)
 int msm_amd_f_to_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
 int msm_amd_f_from_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
 
+/* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
+/* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),
+ * *sign bit 0 = (k1 >= 0), bit 1 = (k2 >= 0), with k = k1 + k2*lambda (mod r).  Host only.               */
+int msm_amd_glv_decompose_scalar(const uint8_t *scalar32, uint8_t *out64, uint32_t *sign);
+/* g1m_glv_endomorphism (:150-163): affine (x, y) -> (beta*x, sign ? y : -y).  Host only.                     */
+int msm_amd_glv_endomorphism(const uint8_t *point_affine, uint32_t sign, uint8_t *out_affine);
+/* g1m_glv_preprocessEndomorphism (:178-267) on the GPU: n (affine point, 32-byte scalar) pairs -> 2n pairs whose
+ * scalars fit 128 bits; msm(points_out, scalars_out, 2n) == msm(points, scalars, n).  flags: MSM_AMD_DEVICE_PTRS. */
+int msm_amd_glv_preprocess(msm_amd_ctx *ctx, uint32_t flags, const void *points, const void *scalars, uint32_t n,
+                           void *points_out, void *scalars_out);
+
 /* ---- device memory + measurement utilities (bench / tests) ------------------------------------- */
 int msm_amd_dev_alloc(msm_amd_ctx *ctx, size_t bytes, void **dev_ptr);
 int msm_amd_dev_free(msm_amd_ctx *ctx, void *dev_ptr);

@@ -30,6 +30,7 @@
 #include "../../include/msm_amd.h"
 #include "engine_common.hpp"
 #include "field_host.hpp"
+#include "glv.hpp"
 
 namespace msm {
 
@@ -512,6 +513,39 @@ __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __res
             a.y = F::mul(p.y, F::mul(zi2, zi));
         }
         store16(aff + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// GLV pre-pass (BLS12-381 G1): build_glv.js:178-267 (_preprocessEndomorphism), one lane per pair.
+//   points_out[2i]   = (x, k1 >= 0 ? y : -y)        scalars_out[2i]   = |k1|  (32 bytes, upper 16 zero)
+//   points_out[2i+1] = (beta*x, k2 >= 0 ? y : -y)   scalars_out[2i+1] = |k2|
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_glv_preprocess(const uint8_t* __restrict__ points, const uint32_t* __restrict__ scalars, uint32_t n,
+                                                         uint8_t* __restrict__ points_out, uint32_t* __restrict__ scalars_out) {
+    using F = Fp<Bls12381Fp>;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t k[8], k1[4], k2[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = scalars[(size_t)i * 8 + j];
+    uint32_t sign = glv::decompose(k, k1, k2);
+    Affine<F> p = load16<Affine<F>>(points + (size_t)i * sizeof(Affine<F>));
+    F beta;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) beta.v[j] = glv::Consts::BETA[j];
+    Affine<F> a{p.x, F::cneg(p.y, (sign & 1u) == 0)};
+    Affine<F> b{F::mul(p.x, beta), F::cneg(p.y, (sign & 2u) == 0)};
+    store16(points_out + (size_t)(2 * i) * sizeof(Affine<F>), Affine<F>::canon(a));
+    store16(points_out + (size_t)(2 * i + 1) * sizeof(Affine<F>), Affine<F>::canon(b));
+    uint32_t* so = scalars_out + (size_t)i * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        so[j] = k1[j];
+        so[4 + j] = 0;
+        so[8 + j] = k2[j];
+        so[12 + j] = 0;
     }
 }
 
@@ -1230,6 +1264,76 @@ int msm_amd_f_from_montgomery(int curve, const uint8_t* in, uint32_t count, uint
     if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, false>(in, count, out);
     if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, false>(in, count, out);
     return MSM_AMD_EINVAL;
+}
+
+// ---- GLV pre-pass (BLS12-381 G1 only, as the reference: build_glv.js:3) ----------------------------
+int msm_amd_glv_decompose_scalar(const uint8_t* scalar32, uint8_t* out64, uint32_t* sign) {
+    if (!scalar32 || !out64 || !sign) return MSM_AMD_EINVAL;
+    uint32_t k[8], k1[4], k2[4];
+    memcpy(k, scalar32, 32);
+    *sign = glv::decompose(k, k1, k2);
+    memset(out64, 0, 64);
+    memcpy(out64, k1, 16);
+    memcpy(out64 + 32, k2, 16);
+    return 0;
+}
+int msm_amd_glv_endomorphism(const uint8_t* point_affine, uint32_t sign, uint8_t* out_affine) {
+    if (!point_affine || !out_affine) return MSM_AMD_EINVAL;
+    using HF = FpH<Bls12381Fp>;
+    HF x, y, beta;
+    memcpy(&x, point_affine, sizeof x);
+    memcpy(&y, point_affine + sizeof x, sizeof y);
+    memcpy(&beta, glv::Consts::BETA, sizeof beta);
+    HF bx = HF::mul(x, beta);
+    HF yy = sign ? y : HF::neg(y);
+    memcpy(out_affine, &bx, sizeof bx);
+    memcpy(out_affine + sizeof bx, &yy, sizeof yy);
+    return 0;
+}
+int msm_amd_glv_preprocess(msm_amd_ctx* ctx, uint32_t flags, const void* points, const void* scalars, uint32_t n, void* points_out,
+                           void* scalars_out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!points || !scalars || !points_out || !scalars_out) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t pb = (size_t)n * 96, sb = (size_t)n * 32;
+    if (flags & MSM_AMD_DEVICE_PTRS) {
+        if (((uintptr_t)points & 15) || ((uintptr_t)points_out & 15) || ((uintptr_t)scalars & 3) || ((uintptr_t)scalars_out & 3)) {
+            ctx->err = "device pointers must be 16-byte (points) / 4-byte (scalars) aligned";
+            return MSM_AMD_EINVAL;
+        }
+        k_glv_preprocess<<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)points, (const uint32_t*)scalars, n, (uint8_t*)points_out,
+                                                          (uint32_t*)scalars_out);
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipGetLastError());
+        return 0;
+    }
+    void *dp = nullptr, *ds = nullptr, *dpo = nullptr, *dso = nullptr;
+    HIPCHK(ctx, hipMalloc(&dp, pb));
+    HIPCHK(ctx, hipMalloc(&ds, sb));
+    HIPCHK(ctx, hipMalloc(&dpo, 2 * pb));
+    HIPCHK(ctx, hipMalloc(&dso, 2 * sb));
+    hipError_t e = hipMemcpyAsync(dp, points, pb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ds, scalars, sb, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_glv_preprocess<<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)dp, (const uint32_t*)ds, n, (uint8_t*)dpo, (uint32_t*)dso);
+        e = hipMemcpyAsync(points_out, dpo, 2 * pb, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(scalars_out, dso, 2 * sb, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dp);
+    (void)hipFree(ds);
+    (void)hipFree(dpo);
+    (void)hipFree(dso);
+    if (e != hipSuccess) {
+        ctx->err = std::string("glv_preprocess: ") + hipGetErrorString(e);
+        return MSM_AMD_EHIP;
+    }
+    return 0;
 }
 
 int msm_amd_dev_alloc(msm_amd_ctx* ctx, size_t bytes, void** dev_ptr) {

@@ -36,6 +36,9 @@ static int (*p_eq)(int, int, const uint8_t *, const uint8_t *);
 static int (*p_combine)(int, int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_to_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
+static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
+static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
+static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
 
 static const char *load_engine(void) {
     if (g_lib) return NULL;
@@ -67,6 +70,9 @@ static const char *load_engine(void) {
     SYM(p_combine, "msm_amd_combine")
     SYM(p_f_to_m, "msm_amd_f_to_montgomery")
     SYM(p_f_from_m, "msm_amd_f_from_montgomery")
+    SYM(p_glv_dec, "msm_amd_glv_decompose_scalar")
+    SYM(p_glv_endo, "msm_amd_glv_endomorphism")
+    SYM(p_glv_pre, "msm_amd_glv_preprocess")
 #undef SYM
     return NULL;
 }
@@ -372,6 +378,89 @@ static napi_value js_mont(napi_env env, napi_callback_info info, int to) {
 static napi_value js_to_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 1); }
 static napi_value js_from_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 0); }
 
+/* ---- GLV pre-pass (bls12381 G1): g1m_glv_decomposeScalar / _endomorphism / _preprocessEndomorphism ---- */
+static napi_value js_glv_decompose(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    const uint8_t *k;
+    size_t lk;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    if (argc < 1 || get_bytes(env, argv[0], &k, &lk) || lk < 32) {
+        napi_throw_type_error(env, NULL, "glvDecomposeScalar(scalar: Uint8Array(32))");
+        return NULL;
+    }
+    uint8_t out[64];
+    uint32_t sign = 0;
+    p_glv_dec(k, out, &sign);
+    napi_value res, jsign, jbytes;
+    NAPI_OK(napi_create_object(env, &res));
+    NAPI_OK(napi_create_uint32(env, sign, &jsign));
+    jbytes = bytes_out(env, out, 64);
+    NAPI_OK(napi_set_named_property(env, res, "sign", jsign));
+    NAPI_OK(napi_set_named_property(env, res, "scalars", jbytes));
+    return res;
+}
+static napi_value js_glv_endomorphism(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    const uint8_t *p;
+    size_t lp;
+    uint32_t sign;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    if (argc < 2 || get_bytes(env, argv[0], &p, &lp) || lp < 96 || get_u32(env, argv[1], &sign)) {
+        napi_throw_type_error(env, NULL, "glvEndomorphism(point: Uint8Array(96), sign)");
+        return NULL;
+    }
+    uint8_t out[96];
+    p_glv_endo(p, sign, out);
+    return bytes_out(env, out, 96);
+}
+static napi_value js_glv_preprocess(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    const uint8_t *pts, *sc;
+    size_t lp, ls;
+    uint32_t n;
+    if (argc < 4 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_bytes(env, argv[1], &pts, &lp) ||
+        get_bytes(env, argv[2], &sc, &ls) || get_u32(env, argv[3], &n) || lp < (size_t)n * 96 || ls < (size_t)n * 32) {
+        napi_throw_type_error(env, NULL, "glvPreprocess(ctx, points: Uint8Array(96 n), scalars: Uint8Array(32 n), n)");
+        return NULL;
+    }
+    uint8_t *po = (uint8_t *)malloc((size_t)n * 192 + 1), *so = (uint8_t *)malloc((size_t)n * 64 + 1);
+    if (!po || !so) {
+        free(po);
+        free(so);
+        napi_throw_error(env, NULL, "out of memory");
+        return NULL;
+    }
+    int rc = p_glv_pre((msm_amd_ctx *)ctx, 0, pts, sc, n, po, so);
+    napi_value res = NULL;
+    if (rc) {
+        napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+    } else {
+        napi_value jp = bytes_out(env, po, (size_t)n * 192), js = bytes_out(env, so, (size_t)n * 64);
+        if (napi_create_object(env, &res) == napi_ok) {
+            napi_set_named_property(env, res, "points", jp);
+            napi_set_named_property(env, res, "scalars", js);
+        }
+    }
+    free(po);
+    free(so);
+    return res;
+}
+
 static napi_value init(napi_env env, napi_value exports) {
     napi_property_descriptor props[] = {
         {"create", NULL, js_create, NULL, NULL, NULL, napi_enumerable, NULL},
@@ -386,6 +475,9 @@ static napi_value init(napi_env env, napi_value exports) {
         {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
         {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"glvPreprocess", NULL, js_glv_preprocess, NULL, NULL, NULL, napi_enumerable, NULL},
     };
     napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
     return exports;

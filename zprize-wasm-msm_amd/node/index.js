@@ -71,6 +71,20 @@ function instantiate(curveName, imports, opts) {
         ex[`${pf}_eq`] = (p1, p2) => (native.eq(C.id, g, u8().subarray(p1, p1 + 3 * fsz), u8().subarray(p2, p2 + 3 * fsz)) ? 1 : 0);
     }
     ex.g1m_multiexp_multiExp = (pPoints, pScalars, n, pr) => ex.g1m_multiexpAffine(pPoints, pScalars, 32, n, pr);
+    if (curveName === "bls12381") {
+        // Manta's GLV exports (wasmcurves/src/build_glv.js:269-272), same pointer conventions
+        ex.g1m_glv_decomposeScalar = (pScalar, pScalarRes) => {
+            const r = native.glvDecomposeScalar(u8().subarray(pScalar, pScalar + 32));
+            u8().set(r.scalars, pScalarRes);
+            return r.sign;
+        };
+        ex.g1m_glv_endomorphism = (pPoint, sign, pPointRes) => u8().set(native.glvEndomorphism(u8().subarray(pPoint, pPoint + 96), sign ? 1 : 0), pPointRes);
+        ex.g1m_glv_preprocessEndomorphism = (pPoints, pScalars, n, pPointsRes, pScalarsRes) => {
+            const r = native.glvPreprocess(ctx, u8().subarray(pPoints, pPoints + 96 * n), u8().subarray(pScalars, pScalars + 32 * n), n);
+            u8().set(r.points, pPointsRes);
+            u8().set(r.scalars, pScalarsRes);
+        };
+    }
     ex.f1m_toMontgomery = (p, pr) => u8().set(native.toMontgomery(C.id, u8().subarray(p, p + C.n8)), pr);
     ex.f1m_fromMontgomery = (p, pr) => u8().set(native.fromMontgomery(C.id, u8().subarray(p, p + C.n8)), pr);
     return ex;

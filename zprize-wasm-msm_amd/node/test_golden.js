@@ -89,6 +89,29 @@ async function main() {
             }
         }
     }
+    // GLV: the reference's known answer (wasmcurves/test/glv.js:50-65) through the export-shaped surface
+    {
+        const kat = JSON.parse(fs.readFileSync(path.join(GOLD, "kats_glv.json")));
+        const r = msm.native.glvDecomposeScalar(bigToLe(BigInt(kat.scalar), 32));
+        const k1 = leToBig(Buffer.from(r.scalars).slice(0, 32)), k2 = leToBig(Buffer.from(r.scalars).slice(32, 64));
+        if (k1.toString() !== kat.expected[0] || k2.toString() !== kat.expected[1] || r.sign !== kat.sign) throw new Error("GLV decomposition KAT differs");
+        checked++;
+        if (!hostOnly) {
+            const memory = new WebAssembly.Memory({ initial: 4 });
+            const m = msm.instantiate("bls12381", { memory });
+            const gold = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_bls12381.json"))).groups.g1;
+            const pool = fs.readFileSync(path.join(GOLD, gold.pool_file));
+            const n = 5, pP = 1024, pS = pP + 96 * n, pPo = pS + 32 * n, pSo = pPo + 192 * n, pR1 = pSo + 64 * n, pR2 = pR1 + 144;
+            const mem = new Uint8Array(memory.buffer);
+            mem.set(pool.slice(0, 96 * n), pP);
+            mem.set(stream("node:glv", 32 * n).map((b, i) => (i % 32 === 31 ? b & 0x3f : b)), pS);
+            m.g1m_glv_preprocessEndomorphism(pP, pS, n, pPo, pSo);
+            m.g1m_multiexpAffine(pPo, pSo, 32, 2 * n, pR1);
+            m.g1m_multiexpAffine(pP, pS, 32, n, pR2);
+            if (!m.g1m_eq(pR1, pR2)) throw new Error("GLV-preprocessed MSM differs from the plain MSM");
+            checked++;
+        }
+    }
     // argument errors are thrown, not swallowed
     let threw = false;
     try { msm.native.normalize(0, 3, new Uint8Array(144)); } catch (e) { threw = true; }

@@ -65,6 +65,9 @@ def load_library(path=None):
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
     L.msm_amd_f_to_montgomery.argtypes = [c.c_int, vp, u32, u8p]
     L.msm_amd_f_from_montgomery.argtypes = [c.c_int, vp, u32, u8p]
+    L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
+    L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
+    L.msm_amd_glv_preprocess.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     L.msm_amd_dev_alloc.argtypes = [vp, c.c_size_t, c.POINTER(vp)]
     L.msm_amd_dev_free.argtypes = [vp, vp]
     L.msm_amd_h2d.argtypes = [vp, vp, vp, c.c_size_t]
@@ -271,6 +274,19 @@ class Curve:
                                                               shard, nshards, ctypes.byref(t)))
         return Ticket(self, group, t.value, (kb, ks))
 
+    # --- GLV pre-pass (bls12381 G1 only): g1m_glv_preprocessEndomorphism ----------------------------------
+    def g1m_glv_preprocessEndomorphism(self, points, scalars, n):
+        if self.name != "bls12381":
+            raise MsmAmdError("the GLV pre-pass exists for bls12381 G1 only (as in the reference)")
+        pp, dev_p, kp = _as_ptr(points)
+        ps, dev_s, ks = _as_ptr(scalars)
+        if dev_p or dev_s:
+            raise MsmAmdError("host buffers expected (use msm_amd_glv_preprocess with MSM_AMD_DEVICE_PTRS from C for resident data)")
+        po = ctypes.create_string_buffer(2 * n * 96)
+        so = ctypes.create_string_buffer(2 * n * 32)
+        self.eng._chk(self.eng.L.msm_amd_glv_preprocess(self.eng.ctx, 0, pp, ps, n, po, so))
+        return po.raw, so.raw
+
     def gen_points(self, group, seed, n):
         buf = self.eng.alloc(max(16, n * self.affine_bytes(group)))
         self.eng._chk(self.eng.L.msm_amd_gen_points(self.eng.ctx, self.cid, group, seed, n, buf.ptr))
@@ -311,6 +327,24 @@ def eq(curve, group, a, b):
     if rc < 0:
         raise MsmAmdError("msm_amd_eq failed")
     return rc == 1
+
+
+def glv_decompose_scalar(scalar32):
+    """g1m_glv_decomposeScalar: returns (|k1| as int, |k2| as int, sign word)"""
+    L = load_library()
+    out = ctypes.create_string_buffer(64)
+    sign = ctypes.c_uint32()
+    if L.msm_amd_glv_decompose_scalar(bytes(scalar32), out, ctypes.byref(sign)):
+        raise MsmAmdError("msm_amd_glv_decompose_scalar failed")
+    return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little"), sign.value
+
+
+def glv_endomorphism(point_affine, sign):
+    L = load_library()
+    out = ctypes.create_string_buffer(96)
+    if L.msm_amd_glv_endomorphism(bytes(point_affine), int(sign), out):
+        raise MsmAmdError("msm_amd_glv_endomorphism failed")
+    return out.raw
 
 
 def f_to_montgomery(curve, data):
