@@ -128,6 +128,17 @@ int msm_amd_eq(int curve, int group, const uint8_t *jac_a, const uint8_t *jac_b)
 int msm_amd_f_to_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
 int msm_amd_f_from_montgomery(int curve, const uint8_t *in, uint32_t count, uint8_t *out);
 
+/* ---- batch conversions either side of the MSM, on the GPU ----------------------- */
+/* g?m_batchToAffine   (build_curve_jacobian_a0.js:1040-1125)  n Jacobian -> n affine; Z == 0 -> (0, 0)
+ * g?m_batchToJacobian (:1014-1038, :1418)                     n affine -> n Jacobian (x, y, R); (0,0) -> (0, R, 0)
+ * g?m_batchLEMtoU     (:1206-1231, :1413)  affine LE-Montgomery -> x || y big-endian, non-Montgomery; infinity = 0x40 00 ...
+ * g?m_batchUtoLEM     (:1233-1258, :1415)  the inverse
+ * flags: MSM_AMD_DEVICE_PTRS when `in` and `out` are GPU buffers (16-byte aligned).                                */
+int msm_amd_batch_to_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *jac_in, uint32_t n, void *aff_out);
+int msm_amd_batch_to_jacobian(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *jac_out);
+int msm_amd_batch_lem_to_u(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *u_out);
+int msm_amd_batch_u_to_lem(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *u_in, uint32_t n, void *aff_out);
+
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),
  * *sign bit 0 = (k1 >= 0), bit 1 = (k2 >= 0), with k = k1 + k2*lambda (mod r).  Host only.               */

@@ -615,6 +615,64 @@ EXPORT int oracle_f_inverse(int curve, int group, const u8 *x, u8 *out) {
     u64 a[MAXE], r[MAXE]; memcpy(a, x, K.nw * 8);
     f_inverse(&K, a, r); memcpy(out, r, K.nw * 8); return 0;
 }
+/* ---- batch conversions either side of the MSM ------------------------------ */
+/* build_curve_jacobian_a0.js:1040-1125 (batchToAffine): (X/Z^2, Y/Z^3); Z == 0 -> (0, 0) */
+EXPORT int oracle_g_batch_to_affine(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    for (u32 i = 0; i < n; i++) {
+        u64 a[3 * MAXE], r[2 * MAXE];
+        memcpy(a, in + (size_t)i * 3 * K.nw * 8, 3 * K.nw * 8);
+        g_to_affine(&K, a, r);
+        memcpy(out + (size_t)i * 2 * K.nw * 8, r, 2 * K.nw * 8);
+    }
+    return 0;
+}
+/* build_curve_jacobian_a0.js:1014-1038,1418 (batchToJacobian) */
+EXPORT int oracle_g_batch_to_jacobian(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    for (u32 i = 0; i < n; i++) {
+        u64 a[2 * MAXE], r[3 * MAXE];
+        memcpy(a, in + (size_t)i * 2 * K.nw * 8, 2 * K.nw * 8);
+        g_to_jacobian(&K, a, r);
+        memcpy(out + (size_t)i * 3 * K.nw * 8, r, 3 * K.nw * 8);
+    }
+    return 0;
+}
+static void reverse_bytes(const u8 *in, size_t n, u8 *out) { for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i]; }
+/* build_curve_jacobian_a0.js:1206-1231,1413 (LEMtoU / batchLEMtoU): affine little-endian Montgomery ->
+ * x || y big-endian plain; infinity -> zeros with first byte 0x40 */
+EXPORT int oracle_g_batch_lem_to_u(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    size_t fsz = (size_t)K.nw * 8, n8 = (size_t)K.fp->n64 * 8;
+    for (u32 i = 0; i < n; i++) {
+        u64 a[2 * MAXE]; u8 pl[2 * MAXE * 8];
+        memcpy(a, in + (size_t)i * 2 * fsz, 2 * fsz);
+        u8 *o = out + (size_t)i * 2 * fsz;
+        if (g_is_zero_affine(&K, a)) { memset(o, 0, 2 * fsz); o[0] = 0x40; continue; }
+        for (int c = 0; c < 2 * K.deg; c++) {
+            u64 t[MAXW]; fp_from_mont(K.fp, a + c * K.fp->n64, t); memcpy(pl + c * n8, t, n8);
+        }
+        reverse_bytes(pl, fsz, o);
+        reverse_bytes(pl + fsz, fsz, o + fsz);
+    }
+    return 0;
+}
+/* build_curve_jacobian_a0.js:1233-1258,1415 (UtoLEM / batchUtoLEM) */
+EXPORT int oracle_g_batch_u_to_lem(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    size_t fsz = (size_t)K.nw * 8, n8 = (size_t)K.fp->n64 * 8;
+    for (u32 i = 0; i < n; i++) {
+        const u8 *p = in + (size_t)i * 2 * fsz; u8 *o = out + (size_t)i * 2 * fsz; u8 pl[2 * MAXE * 8];
+        if (p[0] & 0x40) { memset(o, 0, 2 * fsz); continue; }
+        reverse_bytes(p, fsz, pl);
+        reverse_bytes(p + fsz, fsz, pl + fsz);
+        for (int c = 0; c < 2 * K.deg; c++) {
+            u64 t[MAXW], r[MAXW]; memcpy(t, pl + c * n8, n8); fp_to_mont(K.fp, t, r); memcpy(o + c * n8, r, n8);
+        }
+    }
+    return 0;
+}
+
 /* base-field conversions (f1m_toMontgomery / f1m_fromMontgomery) applied per Fp component */
 EXPORT int oracle_f_to_montgomery(int curve, const u8 *x, u32 count, u8 *out) {
     ensure_init(); if (curve < 0 || curve > 1) return -1;

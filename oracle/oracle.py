@@ -113,6 +113,18 @@ class Oracle:
         assert self.L.oracle_g_batch_times_scalar_affine(self.cid, self.group, bytes(p), bytes(scalars), scalar_len, n, out) == 0
         return out.raw
 
+    # --- batch conversions either side of the MSM (batchToAffine, batchToJacobian, batchLEMtoU, batchUtoLEM) ---
+    def _batch(self, fn, data, in_sz, out_sz):
+        n = len(data) // in_sz
+        out = _buf(max(1, n * out_sz))
+        assert getattr(self.L, fn)(self.cid, self.group, bytes(data), n, out) == 0
+        return out.raw[:n * out_sz]
+
+    def batch_to_affine(self, jac): return self._batch("oracle_g_batch_to_affine", jac, self.jsz, self.asz)
+    def batch_to_jacobian(self, aff): return self._batch("oracle_g_batch_to_jacobian", aff, self.asz, self.jsz)
+    def batch_lem_to_u(self, aff): return self._batch("oracle_g_batch_lem_to_u", aff, self.asz, self.asz)
+    def batch_u_to_lem(self, u): return self._batch("oracle_g_batch_u_to_lem", u, self.asz, self.asz)
+
     # --- field ops ---
     def f_mul(self, x, y): return self._g2("oracle_f_mul", x, y, self.fsz)
     def f_add(self, x, y): return self._g2("oracle_f_add", x, y, self.fsz)

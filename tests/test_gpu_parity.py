@@ -225,6 +225,33 @@ def test_randomised_configurations(eng, orc):
         eng.set_option("reduce_l", 0)
 
 
+def test_batch_conversions(eng, orc):
+    """g?m_batchToAffine / _batchToJacobian / _batchLEMtoU / _batchUtoLEM on the GPU: byte-equal to the reference's
+    outputs (tests/golden/golden_conv.json) and to the oracle on a larger seeded batch."""
+    import json
+    with open(os.path.join(gu.GOLDEN, "golden_conv.json")) as f:
+        conv = json.load(f)
+    for c in conv["cases"]:
+        C = eng.curve(c["curve"])
+        g = c["group"]
+        jac, aff = bytes.fromhex(c["jacobian_in"]), bytes.fromhex(c["affine_in"])
+        assert getattr(C, f"g{g}m_batchToAffine")(jac).hex() == c["batchToAffine"]
+        assert getattr(C, f"g{g}m_batchToJacobian")(aff).hex() == c["batchToJacobian"]
+        u = getattr(C, f"g{g}m_batchLEMtoU")(aff)
+        assert u.hex() == c["batchLEMtoU"]
+        assert getattr(C, f"g{g}m_batchUtoLEM")(u).hex() == c["batchUtoLEM_of_U"]
+        # larger batch against the oracle (1000 points incl. repeated infinities; not a multiple of the lane batch)
+        O = orc.Oracle(c["curve"], g)
+        n = 1003
+        big_aff = (aff * (n // c["n"] + 1))[:n * O.asz]
+        big_jac = (jac * (n // c["n"] + 1))[:n * O.jsz]
+        assert getattr(C, f"g{g}m_batchToAffine")(big_jac) == O.batch_to_affine(big_jac)
+        assert getattr(C, f"g{g}m_batchToJacobian")(big_aff) == O.batch_to_jacobian(big_aff)
+        assert getattr(C, f"g{g}m_batchLEMtoU")(big_aff) == O.batch_lem_to_u(big_aff)
+        assert getattr(C, f"g{g}m_batchUtoLEM")(O.batch_lem_to_u(big_aff)) == big_aff
+        assert getattr(C, f"g{g}m_batchToAffine")(b"") == b""
+
+
 def test_error_codes(eng):
     import msm_amd
     C = eng.curve("bls12381")

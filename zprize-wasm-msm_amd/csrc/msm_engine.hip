@@ -517,6 +517,84 @@ __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __res
 }
 
 
+
+// ------------------------------------------------------------------------------------------
+// Batch conversions either side of the MSM, one lane per point:
+//   k_batch_to_jacobian   g?m_batchToJacobian  (build_curve_jacobian_a0.js:1014-1038,1418)
+//   k_batch_lem_to_u      g?m_batchLEMtoU      (:1206-1231,1413)  LE Montgomery affine -> x||y big-endian plain, inf = 0x40 00..
+//   k_batch_u_to_lem      g?m_batchUtoLEM      (:1233-1258,1415)
+// (g?m_batchToAffine is k_jacobian_to_affine above.)
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_batch_to_jacobian(const uint8_t* __restrict__ aff, uint32_t n, uint8_t* __restrict__ jac) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load16<Affine<F>>(aff + (size_t)i * sizeof(Affine<F>));
+    Jacobian<F> j;
+    if (p.is_inf()) j = {F::zero(), F::one(), F::zero()};
+    else j = {p.x, p.y, F::one()};
+    store16(jac + (size_t)i * sizeof(Jacobian<F>), j);
+}
+MSM_D uint32_t bswap32(uint32_t v) { return __builtin_bswap32(v); }
+template <class F, class B>
+__global__ void __launch_bounds__(256) k_batch_lem_to_u(const uint8_t* __restrict__ aff, uint32_t n, uint8_t* __restrict__ out) {
+    constexpr int T = sizeof(F) / 4, NB = sizeof(B) / 4, COMP = T / NB;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load16<Affine<F>>(aff + (size_t)i * sizeof(Affine<F>));
+    Affine<F> o;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+    if (p.is_inf()) {
+#pragma unroll
+        for (int k = 0; k < 2 * T; ++k) ow[k] = 0;
+        ow[0] = 0x40u;   // first byte of the output
+    } else {
+        const F* coords[2] = {&p.x, &p.y};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            uint32_t plain[T];
+            const B* comps = reinterpret_cast<const B*>(coords[c]);
+#pragma unroll
+            for (int k = 0; k < COMP; ++k) {
+                B v = B::canon(B::from_mont(comps[k]));
+#pragma unroll
+                for (int l = 0; l < NB; ++l) plain[k * NB + l] = v.v[l];
+            }
+#pragma unroll
+            for (int l = 0; l < T; ++l) ow[c * T + l] = bswap32(plain[T - 1 - l]);
+        }
+    }
+    store16(out + (size_t)i * sizeof(Affine<F>), o);
+}
+template <class F, class B>
+__global__ void __launch_bounds__(256) k_batch_u_to_lem(const uint8_t* __restrict__ in, uint32_t n, uint8_t* __restrict__ aff) {
+    constexpr int T = sizeof(F) / 4, NB = sizeof(B) / 4, COMP = T / NB;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> u = load16<Affine<F>>(in + (size_t)i * sizeof(Affine<F>));
+    const uint32_t* uw = reinterpret_cast<const uint32_t*>(&u);
+    Affine<F> o;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+    if (uw[0] & 0x40u) {
+#pragma unroll
+        for (int k = 0; k < 2 * T; ++k) ow[k] = 0;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int k = 0; k < COMP; ++k) {
+                B v;
+#pragma unroll
+                for (int l = 0; l < NB; ++l) v.v[l] = bswap32(uw[c * T + (T - 1 - (k * NB + l))]);
+                B m = B::canon(B::to_mont(v));
+#pragma unroll
+                for (int l = 0; l < NB; ++l) ow[c * T + k * NB + l] = m.v[l];
+            }
+        }
+    }
+    store16(aff + (size_t)i * sizeof(Affine<F>), o);
+}
+
 // ------------------------------------------------------------------------------------------
 // GLV pre-pass (BLS12-381 G1): build_glv.js:178-267 (_preprocessEndomorphism), one lane per pair.
 //   points_out[2i]   = (x, k1 >= 0 ? y : -y)        scalars_out[2i]   = |k1|  (32 bytes, upper 16 zero)
@@ -1092,6 +1170,63 @@ static int f_conv(const uint8_t* in, uint32_t count, uint8_t* out) {
     return 0;
 }
 
+
+// ---- batch conversions (g?m_batchToAffine / _batchToJacobian / _batchLEMtoU / _batchUtoLEM) ----------------
+template <class F, class B>
+static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, uint32_t n, void* out) {
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
+    const size_t in_b = (size_t)n * (which == 0 ? JSZ : ASZ), out_b = (size_t)n * (which == 1 ? JSZ : ASZ);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    void *di = const_cast<void*>(in), *dout = out;
+    if (dev) {
+        if (((uintptr_t)in & 15) || ((uintptr_t)out & 15)) {
+            ctx->err = "device pointers must be 16-byte aligned";
+            return MSM_AMD_EINVAL;
+        }
+    } else {
+        HIPCHK(ctx, hipMalloc(&di, in_b));
+        if (hipMalloc(&dout, out_b) != hipSuccess) {
+            (void)hipFree(di);
+            ctx->err = "hipMalloc failed";
+            return MSM_AMD_EHIP;
+        }
+        (void)hipMemcpyAsync(di, in, in_b, hipMemcpyHostToDevice, st);
+    }
+    const uint32_t blocks = (n + 255) / 256;
+    if (which == 0) k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    else if (which == 1) k_batch_to_jacobian<F><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    else if (which == 2) k_batch_lem_to_u<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    else k_batch_u_to_lem<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    hipError_t e = hipGetLastError();
+    if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, out_b, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (!dev) {
+        (void)hipFree(di);
+        (void)hipFree(dout);
+    }
+    if (e != hipSuccess) {
+        ctx->err = std::string("batch conversion: ") + hipGetErrorString(e);
+        return MSM_AMD_EHIP;
+    }
+    return 0;
+}
+static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flags, const void* in, uint32_t n, void* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !out) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 1) return conv_t<Fp<Bls12381Fp>, Fp<Bls12381Fp>>(ctx, which, flags, in, n, out);
+    if (curve == MSM_AMD_BLS12381 && group == 2) return conv_t<Fp2<Bls12381Fp>, Fp<Bls12381Fp>>(ctx, which, flags, in, n, out);
+    if (curve == MSM_AMD_BN128 && group == 1) return conv_t<Fp<Bn254Fp>, Fp<Bn254Fp>>(ctx, which, flags, in, n, out);
+    if (curve == MSM_AMD_BN128 && group == 2) return conv_t<Fp2<Bn254Fp>, Fp<Bn254Fp>>(ctx, which, flags, in, n, out);
+    ctx->err = "unknown curve/group";
+    return MSM_AMD_EINVAL;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -1264,6 +1399,19 @@ int msm_amd_f_from_montgomery(int curve, const uint8_t* in, uint32_t count, uint
     if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, false>(in, count, out);
     if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, false>(in, count, out);
     return MSM_AMD_EINVAL;
+}
+
+int msm_amd_batch_to_affine(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* jac_in, uint32_t n, void* aff_out) {
+    return conv(ctx, 0, curve, group, flags, jac_in, n, aff_out);
+}
+int msm_amd_batch_to_jacobian(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* aff_in, uint32_t n, void* jac_out) {
+    return conv(ctx, 1, curve, group, flags, aff_in, n, jac_out);
+}
+int msm_amd_batch_lem_to_u(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* aff_in, uint32_t n, void* u_out) {
+    return conv(ctx, 2, curve, group, flags, aff_in, n, u_out);
+}
+int msm_amd_batch_u_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* u_in, uint32_t n, void* aff_out) {
+    return conv(ctx, 3, curve, group, flags, u_in, n, aff_out);
 }
 
 // ---- GLV pre-pass (BLS12-381 G1 only, as the reference: build_glv.js:3) ----------------------------

@@ -36,6 +36,7 @@ static int (*p_eq)(int, int, const uint8_t *, const uint8_t *);
 static int (*p_combine)(int, int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_to_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
+static int (*p_conv[4])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
 static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
@@ -70,6 +71,10 @@ static const char *load_engine(void) {
     SYM(p_combine, "msm_amd_combine")
     SYM(p_f_to_m, "msm_amd_f_to_montgomery")
     SYM(p_f_from_m, "msm_amd_f_from_montgomery")
+    SYM(p_conv[0], "msm_amd_batch_to_affine")
+    SYM(p_conv[1], "msm_amd_batch_to_jacobian")
+    SYM(p_conv[2], "msm_amd_batch_lem_to_u")
+    SYM(p_conv[3], "msm_amd_batch_u_to_lem")
     SYM(p_glv_dec, "msm_amd_glv_decompose_scalar")
     SYM(p_glv_endo, "msm_amd_glv_endomorphism")
     SYM(p_glv_pre, "msm_amd_glv_preprocess")
@@ -378,6 +383,39 @@ static napi_value js_mont(napi_env env, napi_callback_info info, int to) {
 static napi_value js_to_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 1); }
 static napi_value js_from_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 0); }
 
+/* ---- batch conversions: batchConvert(ctx, which, curve, group, bytes) -> bytes
+ *      which: 0 batchToAffine, 1 batchToJacobian, 2 batchLEMtoU, 3 batchUtoLEM ---------------------------- */
+static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int which, curve, group;
+    const uint8_t *in;
+    size_t lin;
+    if (argc < 5 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &which) || get_i32(env, argv[2], &curve) ||
+        get_i32(env, argv[3], &group) || get_bytes(env, argv[4], &in, &lin) || which < 0 || which > 3 || (curve != 0 && curve != 1) ||
+        (group != 1 && group != 2)) {
+        napi_throw_type_error(env, NULL, "batchConvert(ctx, which 0..3, curve, group, Uint8Array)");
+        return NULL;
+    }
+    size_t fsz = (size_t)n8_of(curve) * group;
+    size_t in_sz = (which == 0 ? 3 : 2) * fsz, out_sz = (which == 1 ? 3 : 2) * fsz;
+    if (lin % in_sz) {
+        napi_throw_range_error(env, NULL, "input is not a whole number of points");
+        return NULL;
+    }
+    uint32_t n = (uint32_t)(lin / in_sz);
+    uint8_t *out = (uint8_t *)malloc((size_t)n * out_sz + 1);
+    if (!out) return NULL;
+    int rc = p_conv[which]((msm_amd_ctx *)ctx, curve, group, 0, in, n, out);
+    napi_value res = NULL;
+    if (rc) napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+    else res = bytes_out(env, out, (size_t)n * out_sz);
+    free(out);
+    return res;
+}
+
 /* ---- GLV pre-pass (bls12381 G1): g1m_glv_decomposeScalar / _endomorphism / _preprocessEndomorphism ---- */
 static napi_value js_glv_decompose(napi_env env, napi_callback_info info) {
     size_t argc = 1;
@@ -475,6 +513,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
         {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvPreprocess", NULL, js_glv_preprocess, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -65,6 +65,12 @@ function instantiate(curveName, imports, opts) {
         ex[`${pf}_multiexpAffine`] = mk(0, false);
         ex[`${pf}_multiexp_chunk`] = mk(FLAG_JACOBIAN, true);
         ex[`${pf}_multiexpAffine_chunk`] = mk(0, true);
+        // batch conversions either side of the MSM (same (pIn, n, pOut) signature as the reference's exports)
+        const conv = (which, inSz, outSz) => (pIn, n, pOut) => u8().set(native.batchConvert(ctx, which, C.id, g, u8().subarray(pIn, pIn + n * inSz)), pOut);
+        ex[`${pf}_batchToAffine`] = conv(0, 3 * fsz, 2 * fsz);
+        ex[`${pf}_batchToJacobian`] = conv(1, 2 * fsz, 3 * fsz);
+        ex[`${pf}_batchLEMtoU`] = conv(2, 2 * fsz, 2 * fsz);
+        ex[`${pf}_batchUtoLEM`] = conv(3, 2 * fsz, 2 * fsz);
         // comparison helpers the reference's tests use around the MSM
         ex[`${pf}_normalize`] = (p, pr) => u8().set(native.normalize(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);
         ex[`${pf}_toAffine`] = (p, pr) => u8().set(native.toAffine(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);

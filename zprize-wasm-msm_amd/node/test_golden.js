@@ -89,6 +89,23 @@ async function main() {
             }
         }
     }
+    // batch conversions through the export-shaped surface (tests/golden/golden_conv.json)
+    if (!hostOnly) {
+        const conv = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_conv.json")));
+        for (const c of conv.cases) {
+            const memory = new WebAssembly.Memory({ initial: 8 });
+            const m = msm.instantiate(c.curve, { memory });
+            const jac = Buffer.from(c.jacobian_in, "hex"), aff = Buffer.from(c.affine_in, "hex");
+            const pJ = 1024, pA = pJ + jac.length, pO = pA + aff.length, pf = `g${c.group}m`;
+            new Uint8Array(memory.buffer).set(jac, pJ); new Uint8Array(memory.buffer).set(aff, pA);
+            const grab = (len) => Buffer.from(new Uint8Array(memory.buffer).slice(pO, pO + len)).toString("hex");
+            m[`${pf}_batchToAffine`](pJ, c.n, pO); if (grab(aff.length) !== c.batchToAffine) throw new Error("batchToAffine differs");
+            m[`${pf}_batchToJacobian`](pA, c.n, pO); if (grab(jac.length) !== c.batchToJacobian) throw new Error("batchToJacobian differs");
+            m[`${pf}_batchLEMtoU`](pA, c.n, pO); if (grab(aff.length) !== c.batchLEMtoU) throw new Error("batchLEMtoU differs");
+            m[`${pf}_batchUtoLEM`](pO, c.n, pJ); if (Buffer.from(new Uint8Array(memory.buffer).slice(pJ, pJ + aff.length)).toString("hex") !== c.affine_in) throw new Error("batchUtoLEM differs");
+            checked += 4;
+        }
+    }
     // GLV: the reference's known answer (wasmcurves/test/glv.js:50-65) through the export-shaped surface
     {
         const kat = JSON.parse(fs.readFileSync(path.join(GOLD, "kats_glv.json")));

@@ -65,6 +65,8 @@ def load_library(path=None):
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
     L.msm_amd_f_to_montgomery.argtypes = [c.c_int, vp, u32, u8p]
     L.msm_amd_f_from_montgomery.argtypes = [c.c_int, vp, u32, u8p]
+    for _fn in ("msm_amd_batch_to_affine", "msm_amd_batch_to_jacobian", "msm_amd_batch_lem_to_u", "msm_amd_batch_u_to_lem"):
+        getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
     L.msm_amd_glv_preprocess.argtypes = [vp, u32, vp, vp, u32, vp, vp]
@@ -273,6 +275,23 @@ class Curve:
         self.eng._chk(self.eng.L.msm_amd_multiexp_shard_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
                                                               shard, nshards, ctypes.byref(t)))
         return Ticket(self, group, t.value, (kb, ks))
+
+    # --- batch conversions either side of the MSM (the reference's g?m_batch* exports), host buffers ---------
+    def _conv(self, fn, group, data, in_sz, out_sz):
+        data = bytes(data)
+        n = len(data) // in_sz
+        out = ctypes.create_string_buffer(max(1, n * out_sz))
+        self.eng._chk(getattr(self.eng.L, fn)(self.eng.ctx, self.cid, group, 0, data, n, out))
+        return out.raw[:n * out_sz]
+
+    def g1m_batchToAffine(self, jac): return self._conv("msm_amd_batch_to_affine", 1, jac, self.jacobian_bytes(1), self.affine_bytes(1))
+    def g2m_batchToAffine(self, jac): return self._conv("msm_amd_batch_to_affine", 2, jac, self.jacobian_bytes(2), self.affine_bytes(2))
+    def g1m_batchToJacobian(self, aff): return self._conv("msm_amd_batch_to_jacobian", 1, aff, self.affine_bytes(1), self.jacobian_bytes(1))
+    def g2m_batchToJacobian(self, aff): return self._conv("msm_amd_batch_to_jacobian", 2, aff, self.affine_bytes(2), self.jacobian_bytes(2))
+    def g1m_batchLEMtoU(self, aff): return self._conv("msm_amd_batch_lem_to_u", 1, aff, self.affine_bytes(1), self.affine_bytes(1))
+    def g2m_batchLEMtoU(self, aff): return self._conv("msm_amd_batch_lem_to_u", 2, aff, self.affine_bytes(2), self.affine_bytes(2))
+    def g1m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 1, u, self.affine_bytes(1), self.affine_bytes(1))
+    def g2m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 2, u, self.affine_bytes(2), self.affine_bytes(2))
 
     # --- GLV pre-pass (bls12381 G1 only): g1m_glv_preprocessEndomorphism ----------------------------------
     def g1m_glv_preprocessEndomorphism(self, points, scalars, n):
