@@ -184,7 +184,7 @@ def main():
             "metric": "BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}",
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if world > 1 else "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)" if args.curve == "bls12381" else "u32 limbs (254-bit Montgomery integers)",
             "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); inputs resident in HBM",
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
@@ -198,6 +198,11 @@ def main():
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms},
+            # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  2750 v_mad_u64_u32 per
+            # bucket addition (8 multiplies x 288 + 2 squarings x 222) against the measured full-rate peak of 36.3 T mad/s
+            # (profiles/r01_valu_rates_microbench.txt); every mad is paired with a v_addc_co_u32, so ~50 % is the ceiling.
+            "roofline_valu": ({"kernel": "k_accumulate", "achieved": geom["entries"] * 2750 / (acc_ms * 1e-3) / 1e12, "peak": 36.3, "unit": "T mad/s",
+                               "frac": geom["entries"] * 2750 / (acc_ms * 1e-3) / 1e12 / 36.3} if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
             "stages_ms": stages,
             "result_x_prefix": result[:8].hex(),
         }

@@ -66,7 +66,8 @@ const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
 /* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
  * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
- * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight). */
+ * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight),
+ * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 
 /* ---- generic entry points -------------------------------------------------------------------- */

@@ -205,6 +205,7 @@ def test_randomised_configurations(eng, orc):
             eng.set_window_bits(rnd.choice([0, 0, 1, 3, 4, 7, 11, 16]))
             eng.set_option("segment", rnd.choice([0, 0, 1, 2, 5, 64]))
             eng.set_option("reduce_l", rnd.choice([0, 0, 1, 3, 16]))
+            eng.set_option("split", rnd.choice([0, 1]))
             mode = rnd.choice(["full", "full", "chunk", "shard"])
             if mode == "full":
                 exp = O.normalize(O.multiexp_affine(bases, scalars, ss, n))
@@ -223,6 +224,7 @@ def test_randomised_configurations(eng, orc):
         eng.set_window_bits(0)
         eng.set_option("segment", 0)
         eng.set_option("reduce_l", 0)
+        eng.set_option("split", 0)
 
 
 def test_batch_conversions(eng, orc):
@@ -250,6 +252,21 @@ def test_batch_conversions(eng, orc):
         assert getattr(C, f"g{g}m_batchLEMtoU")(big_aff) == O.batch_lem_to_u(big_aff)
         assert getattr(C, f"g{g}m_batchUtoLEM")(O.batch_lem_to_u(big_aff)) == big_aff
         assert getattr(C, f"g{g}m_batchToAffine")(b"") == b""
+
+
+def test_split_window_groups(eng, orc):
+    """Option "split": the windows of a lone call accumulated and reduced as two overlapping groups -- same result."""
+    curve, group, n = "bls12381", 1, 6000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, scalars = gu.random_case(curve, group, "gpu:split", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    eng.set_option("split", 1)
+    try:
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp
+        assert eng.geometry()["c"] == 16
+    finally:
+        eng.set_option("split", 0)
 
 
 def test_error_codes(eng):

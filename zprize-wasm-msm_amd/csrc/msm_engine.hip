@@ -428,20 +428,28 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __res
 
 // Ordering of buckets by population (descending), counting sort on min(count, ORDER_BINS-1).
 constexpr int ORDER_BINS = 1024;
-__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ bins) {
-    __shared__ uint32_t h[ORDER_BINS];
+// Sort key: (bucket >= split ? 1 : 0, size class).  With split < nb the order array comes out as
+// [buckets of the first window group by falling population][buckets of the second group by falling population],
+// which lets the engine accumulate and reduce the two groups in two overlapping waves (see submit_msm).
+constexpr int ORDER_KEYS = 2 * ORDER_BINS;
+MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split) {
+    return (b >= split ? (uint32_t)ORDER_BINS : 0u) + ((ORDER_BINS - 1) - min(cnt, (uint32_t)(ORDER_BINS - 1)));   // big buckets first
+}
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ bins) {
+    __shared__ uint32_t h[ORDER_KEYS];
     h[threadIdx.x] = 0;
+    h[threadIdx.x + ORDER_BINS] = 0;
     __syncthreads();
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) {
-        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));   // big buckets first
-        atomicAdd(&h[cls], 1u);
-    }
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) atomicAdd(&h[order_key(b, count[b], split)], 1u);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x + ORDER_BINS]) atomicAdd(&bins[threadIdx.x + ORDER_BINS], h[threadIdx.x + ORDER_BINS]);
 }
 __global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ bins) {
     __shared__ uint32_t buf[ORDER_BINS];
-    uint32_t v = bins[threadIdx.x];
+    // two keys per lane (2t, 2t+1), then a scan over the pair sums
+    uint32_t a = bins[2 * threadIdx.x], b = bins[2 * threadIdx.x + 1];
+    uint32_t v = a + b;
     buf[threadIdx.x] = v;
     __syncthreads();
     for (int d = 1; d < ORDER_BINS; d <<= 1) {
@@ -450,29 +458,30 @@ __global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ bins
         buf[threadIdx.x] += t;
         __syncthreads();
     }
-    bins[threadIdx.x] = buf[threadIdx.x] - v;
+    uint32_t excl = buf[threadIdx.x] - v;
+    bins[2 * threadIdx.x] = excl;
+    bins[2 * threadIdx.x + 1] = excl + a;
 }
-__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ bins,
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ bins,
                                                          uint32_t* __restrict__ order) {
-    __shared__ uint32_t h[ORDER_BINS];
-    __shared__ uint32_t basep[ORDER_BINS];
+    __shared__ uint32_t h[ORDER_KEYS];
+    __shared__ uint32_t basep[ORDER_KEYS];
     h[threadIdx.x] = 0;
+    h[threadIdx.x + ORDER_BINS] = 0;
     __syncthreads();
     // each workgroup owns a contiguous span of buckets
     uint32_t per = (nb + gridDim.x - 1) / gridDim.x;
     uint32_t lo = blockIdx.x * per, hi = min(nb, lo + per);
-    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
-        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));
-        atomicAdd(&h[cls], 1u);
-    }
+    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) atomicAdd(&h[order_key(b, count[b], split)], 1u);
     __syncthreads();
-    basep[threadIdx.x] = h[threadIdx.x] ? atomicAdd(&bins[threadIdx.x], h[threadIdx.x]) : 0;
+    for (uint32_t k = threadIdx.x; k < ORDER_KEYS; k += ORDER_BINS) basep[k] = h[k] ? atomicAdd(&bins[k], h[k]) : 0;
     __syncthreads();
     h[threadIdx.x] = 0;
+    h[threadIdx.x + ORDER_BINS] = 0;
     __syncthreads();
     for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
-        uint32_t cls = (ORDER_BINS - 1) - min(count[b], (uint32_t)(ORDER_BINS - 1));
-        uint32_t p = basep[cls] + atomicAdd(&h[cls], 1u);
+        uint32_t key = order_key(b, count[b], split);
+        uint32_t p = basep[key] + atomicAdd(&h[key], 1u);
         order[p] = b;
     }
 }
@@ -675,6 +684,9 @@ struct Slot {
     size_t h_partials_cap = 0;
     hipEvent_t ev[9] = {};        // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency)
     hipStream_t stream_b = nullptr;   // B: this slot's bucket reduction + partials to host
+    hipStream_t stream_c = nullptr;   // C: reduction of the second window group when a lone call is split in two
+    hipEvent_t ev_c = nullptr;        // second group's reduction done
+    std::vector<uint32_t> part_off, part_cnt;   // per owned window: first partial, number of partials
     bool pending = false;
     bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
     uint64_t ticket = 0;
@@ -698,6 +710,7 @@ struct msm_amd_ctx {
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
     float timings[8] = {};
     uint32_t geometry[6] = {};
@@ -869,7 +882,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_cursor, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_bins, ORDER_BINS * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * XSZ)) return rc;
@@ -883,7 +896,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 
     const uint32_t nblk = (a.n + 255) / 256;
     const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
-    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_BINS * 4, st));
+    // A lone call (nothing else in flight) is latency-bound at its end: the bucket reduction is ~40 dependent additions deep
+    // on one wave per SIMD.  Optionally (option "split") its windows are handled as two groups, the reduction of the first
+    // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
+    // reduction waves leave room for only one accumulation wave per SIMD, and two launches have two tails.  Kept for
+    // experiments, off by default; overlapping across calls (slots) is what pays.
+    bool others_pending = false;
+    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
+    const bool split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
+    const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
+    const uint32_t split = w_split * g.half;                                               // first bucket of the second group
+    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_KEYS * 4, st));
     if (ctx->sort_atomic) {
         // ---- 1. digits + histogram (global atomics)
         HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
@@ -894,9 +917,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
         k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
         k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
-        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
-        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. scatter
         if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
@@ -935,9 +958,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
         k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, Mscan, tmp);
         k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
-        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, bins);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
-        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, bins, order);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
     // ---- 4. accumulate
@@ -954,24 +977,41 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
     uint32_t tail_block = 256;
     while ((size_t)tail_block * XSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
-    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, NB, (uint8_t*)sl->d_buckets.p, seg, sl->d_tailctl.p, sl->d_work.p,
-                          sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
+    uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
+    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                          (uint8_t*)sl->d_segout.p, tail_block);
+    HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
+    if (split < NB) {
+        HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+        launch_accumulate<FK>(st, d_bases, sorted, offset, count, order + split, NB - split, buckets, seg, sl->d_tailctl.p, sl->d_work.p,
+                              sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
+    }
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
-    // ---- 5. reduce (stream B: overlaps the next call's sort + accumulation on stream A)
+    // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
     hipStream_t sb = sl->stream_b;
-    HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[5], 0));
-    // buckets per lane: 8 when every window is owned (throughput), fewer when a shard owns few windows (latency)
-    // ... and 16 when another call is already in flight: its latency is hidden behind that call's accumulation,
-    // and fewer, longer lanes cost less SIMD time (profiles: 3.99 -> 3.91 ms per pipelined call at n = 2^20)
-    bool others_pending = false;
-    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
-    uint32_t L = ctx->force_L ? ctx->force_L : std::min(others_pending ? 16u : 8u, std::max(1u, NB / 65536u));
-    uint32_t lanes_per_window = (g.half + L - 1) / L;
-    uint32_t rblock = std::min(256u, std::max(64u, lanes_per_window));
-    // LDS budget: rblock * XSZ must fit in 64 KB (default limit); shrink for wide fields
-    while ((size_t)rblock * XSZ > 64 * 1024 && rblock > 64) rblock /= 2;
-    uint32_t wgs_per_window = (lanes_per_window + rblock - 1) / rblock;
-    uint32_t nparts = g.Wl * wgs_per_window;
+    // buckets per lane: 8 when every window is owned (throughput), fewer when few windows are reduced at once (latency),
+    // 16 when another call is already in flight: its latency is hidden behind that call's accumulation, and fewer,
+    // longer lanes cost less SIMD time (profiles: 3.99 -> 3.91 ms per pipelined call at n = 2^20)
+    struct Plan {
+        uint32_t L, lanes, rblock, wgs;
+    };
+    auto plan = [&](uint32_t nbuckets) {
+        Plan p;
+        p.L = ctx->force_L ? ctx->force_L : std::min(others_pending ? 16u : 8u, std::max(1u, (nbuckets + 65535u) / 65536u));
+        p.lanes = (g.half + p.L - 1) / p.L;
+        p.rblock = std::min(256u, std::max(64u, p.lanes));
+        while ((size_t)p.rblock * XSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
+        p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
+        return p;
+    };
+    const Plan p0 = plan(split), p1 = plan(NB - split);
+    const uint32_t nparts0 = w_split * p0.wgs, nparts1 = (g.Wl - w_split) * p1.wgs, nparts = nparts0 + nparts1;
+    sl->part_off.assign(g.Wl, 0);
+    sl->part_cnt.assign(g.Wl, 0);
+    for (uint32_t wl = 0; wl < g.Wl; ++wl) {
+        sl->part_off[wl] = wl < w_split ? wl * p0.wgs : nparts0 + (wl - w_split) * p1.wgs;
+        sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
+    }
     if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ)) return rc;
     if (sl->h_partials_cap < (size_t)nparts * XSZ + 16) {
         if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
@@ -980,8 +1020,16 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         HIPCHK(ctx, hipHostMalloc(&sl->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
         sl->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
     }
-    launch_bucket_reduce<FK>(sb, nparts, rblock, (const uint8_t*)sl->d_buckets.p, g.half, L, lanes_per_window, wgs_per_window,
-                             (uint8_t*)sl->d_partials.p);
+    uint8_t* partials = (uint8_t*)sl->d_partials.p;
+    HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
+    launch_bucket_reduce<FK>(sb, nparts0, p0.rblock, buckets, g.half, p0.L, p0.lanes, p0.wgs, partials);
+    if (nparts1) {
+        hipStream_t sc = sl->stream_c;
+        HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
+        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * XSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ);
+        HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
+        HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
+    }
     HIPCHK(ctx, hipEventRecord(sl->ev[6], sb));
     HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, sb));
     // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
@@ -989,6 +1037,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
+    const uint32_t wgs_per_window = p0.wgs;
     sl->wgs_per_window = wgs_per_window;
     sl->nparts = nparts;
     sl->NB = NB;
@@ -1013,7 +1062,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipEventSynchronize(sl->ev[7]));
-    const uint32_t wgs_per_window = sl->wgs_per_window, nparts = sl->nparts;
+    const uint32_t nparts = sl->nparts;
     uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
     {
         uint64_t entries = (uint64_t)h_tail[0] + h_tail[1];
@@ -1034,7 +1083,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         if (prev_w >= 0)
             for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = HX::dbl(total);
         HX s = HX::inf();
-        for (uint32_t k = 0; k < wgs_per_window; ++k) s = HX::add(s, parts[(size_t)wl * wgs_per_window + k]);
+        for (uint32_t k = 0; k < sl->part_cnt[wl]; ++k) s = HX::add(s, parts[(size_t)sl->part_off[wl] + k]);
         total = HX::add(total, s);
         prev_w = wglob;
     }
@@ -1249,7 +1298,8 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
         return MSM_AMD_EHIP;
     }
     for (Slot& sl : ctx->slots) {
-        if (hipStreamCreateWithFlags(&sl.stream_b, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&sl.stream_b, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&sl.stream_c, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sl.ev_c) != hipSuccess) {
             delete ctx;
             return MSM_AMD_EHIP;
         }
@@ -1272,6 +1322,11 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
             (void)hipStreamSynchronize(sl.stream_b);
             (void)hipStreamDestroy(sl.stream_b);
         }
+        if (sl.stream_c) {
+            (void)hipStreamSynchronize(sl.stream_c);
+            (void)hipStreamDestroy(sl.stream_c);
+        }
+        if (sl.ev_c) (void)hipEventDestroy(sl.ev_c);
         for (DevBuf* b : sl.bufs)
             if (b->p) (void)hipFree(b->p);
         if (sl.h_partials) (void)hipHostFree(sl.h_partials);
@@ -1290,6 +1345,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
     if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
     if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
+    if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "slots")) {
         if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 4]"; return MSM_AMD_EINVAL; }
         for (Slot& sl : ctx->slots)
