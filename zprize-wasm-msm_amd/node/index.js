@@ -114,6 +114,11 @@ function curve(curveName, opts) {
             F: { n8: fsz },
             multiExp: run(FLAG_JACOBIAN, 3 * fsz),
             multiExpAffine: run(0, 2 * fsz),
+            // buffer-in / buffer-out forms of the batch conversions (ffjavascript exposes them under these names)
+            batchToAffine: async (buff) => native.batchConvert(ctx, 0, C.id, g, buff),
+            batchToJacobian: async (buff) => native.batchConvert(ctx, 1, C.id, g, buff),
+            batchLEMtoU: async (buff) => native.batchConvert(ctx, 2, C.id, g, buff),
+            batchUtoLEM: async (buff) => native.batchConvert(ctx, 3, C.id, g, buff),
             normalize: (p) => native.normalize(C.id, g, p),
             toAffine: (p) => native.toAffine(C.id, g, p),
             eq: (a, b) => native.eq(C.id, g, a, b),
