@@ -139,6 +139,10 @@ int msm_amd_batch_to_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t fla
 int msm_amd_batch_to_jacobian(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *jac_out);
 int msm_amd_batch_lem_to_u(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *u_out);
 int msm_amd_batch_u_to_lem(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *u_in, uint32_t n, void *aff_out);
+/* g?m_inCurveAffine (:1330-1353) over a batch: out_flags[i] = 1 iff y^2 == x^3 + b for affine point i ((0,0) gives 0, as
+ * in the reference).  out_flags is a host buffer of n bytes unless MSM_AMD_DEVICE_PTRS is set.                           */
+int msm_amd_batch_in_curve_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *points, uint32_t n,
+                                  uint8_t *out_flags);
 
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),

@@ -50,7 +50,17 @@ const hex = (b) => Buffer.from(b).toString("hex");
             const lemToU = Buffer.from(u8().slice(pU, pU + N * asz));
             ex[pf + "_batchUtoLEM"](pU, N, pBack);
             const uToLem = Buffer.from(u8().slice(pBack, pBack + N * asz));
-            result.cases.push({ curve: curveName, group: g, n: N, jacobian_in: hex(jacIn), affine_in: hex(affIn), batchToAffine: hex(toAffine),
+            // inCurveAffine on: the affine inputs (incl. the two infinities) and the same points with x and y swapped
+            const inCurve = [], swapped = Buffer.alloc(N * asz);
+            for (let i = 0; i < N; i++) {
+                inCurve.push(ex[pf + "_inCurveAffine"](pAff + i * asz));
+                affIn.copy(swapped, i * asz, i * asz + fsz, (i + 1) * asz);
+                affIn.copy(swapped, i * asz + fsz, i * asz, i * asz + fsz);
+            }
+            u8().set(swapped, pBack);
+            const inCurveSwapped = [];
+            for (let i = 0; i < N; i++) inCurveSwapped.push(ex[pf + "_inCurveAffine"](pBack + i * asz));
+            result.cases.push({ inCurveAffine: inCurve, swapped_in: hex(swapped), inCurveAffine_swapped: inCurveSwapped, curve: curveName, group: g, n: N, jacobian_in: hex(jacIn), affine_in: hex(affIn), batchToAffine: hex(toAffine),
                 batchToJacobian: hex(toJac), batchLEMtoU: hex(lemToU), batchUtoLEM_of_U: hex(uToLem) });
         }
     }

@@ -638,6 +638,37 @@ EXPORT int oracle_g_batch_to_jacobian(int curve, int group, const u8 *in, u32 n,
     }
     return 0;
 }
+/* build_curve_jacobian_a0.js:1330-1353 (inCurveAffine): y^2 == x^3 + b ; b per curve/group from
+ * bls12381/build_bls12381.js:40-53 (4 ; (4,4)) and bn128/build_bn128.js:35-48 (3 ; the twist constant) */
+static void curve_b(const Fld *K, int curve, u64 *b) {
+    static const char *BN_B2[2] = {"19485874751759354771024239261021720505790618469301721065564631296452457478373",
+                                   "266929791119991161246907387137283842545076965332900288569378510910307636690"};
+    memset(b, 0, K->nw * 8);
+    for (int c = 0; c < K->deg; c++) {
+        u64 plain[MAXW] = {0};
+        if (curve == 0) plain[0] = 4;
+        else if (K->deg == 1) plain[0] = 3;
+        else { /* decimal -> limbs */
+            for (const char *d = BN_B2[c]; *d; d++) {
+                u128 carry = (u128)(*d - '0');
+                for (int i = 0; i < K->fp->n64; i++) { u128 t = (u128)plain[i] * 10 + carry; plain[i] = (u64)t; carry = t >> 64; }
+            }
+        }
+        fp_to_mont(K->fp, plain, b + c * K->fp->n64);
+    }
+}
+EXPORT int oracle_g_batch_in_curve_affine(int curve, int group, const u8 *in, u32 n, u8 *flags) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    u64 b[MAXE]; curve_b(&K, curve, b);
+    for (u32 i = 0; i < n; i++) {
+        u64 a[2 * MAXE], y2[MAXE], x3[MAXE];
+        memcpy(a, in + (size_t)i * 2 * K.nw * 8, 2 * K.nw * 8);
+        f_square(&K, a + K.nw, y2);
+        f_square(&K, a, x3); f_mul(&K, a, x3, x3); f_add(&K, x3, b, x3);
+        flags[i] = (u8)f_eq(&K, y2, x3);
+    }
+    return 0;
+}
 static void reverse_bytes(const u8 *in, size_t n, u8 *out) { for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i]; }
 /* build_curve_jacobian_a0.js:1206-1231,1413 (LEMtoU / batchLEMtoU): affine little-endian Montgomery ->
  * x || y big-endian plain; infinity -> zeros with first byte 0x40 */

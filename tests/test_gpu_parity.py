@@ -252,6 +252,9 @@ def test_batch_conversions(eng, orc):
         assert getattr(C, f"g{g}m_batchLEMtoU")(big_aff) == O.batch_lem_to_u(big_aff)
         assert getattr(C, f"g{g}m_batchUtoLEM")(O.batch_lem_to_u(big_aff)) == big_aff
         assert getattr(C, f"g{g}m_batchToAffine")(b"") == b""
+        assert C.batch_in_curve_affine(g, aff) == c["inCurveAffine"]
+        assert C.batch_in_curve_affine(g, bytes.fromhex(c["swapped_in"])) == c["inCurveAffine_swapped"]
+        assert C.batch_in_curve_affine(g, big_aff) == O.batch_in_curve_affine(big_aff)
 
 
 def test_split_window_groups(eng, orc):

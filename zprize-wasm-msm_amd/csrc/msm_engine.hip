@@ -604,6 +604,19 @@ __global__ void __launch_bounds__(256) k_batch_u_to_lem(const uint8_t* __restric
     store16(aff + (size_t)i * sizeof(Affine<F>), o);
 }
 
+
+// g?m_inCurveAffine (build_curve_jacobian_a0.js:1330-1353) for a batch: flag[i] = (y^2 == x^3 + b).
+// As in the reference, the affine infinity (0, 0) is not "in curve" (0 != b).
+template <class F>
+__global__ void __launch_bounds__(256) k_batch_in_curve_affine(const uint8_t* __restrict__ aff, uint32_t n, F b, uint8_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load16<Affine<F>>(aff + (size_t)i * sizeof(Affine<F>));
+    F y2 = F::sqr(p.y);
+    F x3b = F::add(F::mul(p.x, F::sqr(p.x)), b);
+    flags[i] = F::sub(y2, x3b).is_zero() ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // GLV pre-pass (BLS12-381 G1): build_glv.js:178-267 (_preprocessEndomorphism), one lane per pair.
 //   points_out[2i]   = (x, k1 >= 0 ? y : -y)        scalars_out[2i]   = |k1|  (32 bytes, upper 16 zero)
@@ -1276,6 +1289,43 @@ static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flag
     return MSM_AMD_EINVAL;
 }
 
+
+template <class F>
+static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* points, uint32_t n, uint8_t* out) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const size_t in_b = (size_t)n * sizeof(Affine<F>);
+    void *di = const_cast<void*>(points), *dout = out;
+    if (dev) {
+        if ((uintptr_t)points & 15) {
+            ctx->err = "device points pointer must be 16-byte aligned";
+            return MSM_AMD_EINVAL;
+        }
+    } else {
+        HIPCHK(ctx, hipMalloc(&di, in_b));
+        if (hipMalloc(&dout, n) != hipSuccess) {
+            (void)hipFree(di);
+            ctx->err = "hipMalloc failed";
+            return MSM_AMD_EHIP;
+        }
+        (void)hipMemcpyAsync(di, points, in_b, hipMemcpyHostToDevice, st);
+    }
+    k_batch_in_curve_affine<F><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, b, (uint8_t*)dout);
+    hipError_t e = hipGetLastError();
+    if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (!dev) {
+        (void)hipFree(di);
+        (void)hipFree(dout);
+    }
+    if (e != hipSuccess) {
+        ctx->err = std::string("batch_in_curve_affine: ") + hipGetErrorString(e);
+        return MSM_AMD_EHIP;
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -1468,6 +1518,27 @@ int msm_amd_batch_lem_to_u(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
 }
 int msm_amd_batch_u_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* u_in, uint32_t n, void* aff_out) {
     return conv(ctx, 3, curve, group, flags, u_in, n, aff_out);
+}
+
+int msm_amd_batch_in_curve_affine(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* points, uint32_t n, uint8_t* out_flags) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!points || !out_flags) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 1) return in_curve_t<Fp<Bls12381Fp>>(ctx, fp_from<Bls12381Fp>(Bls12381Fp::B1), flags, points, n, out_flags);
+    if (curve == MSM_AMD_BN128 && group == 1) return in_curve_t<Fp<Bn254Fp>>(ctx, fp_from<Bn254Fp>(Bn254Fp::B1), flags, points, n, out_flags);
+    if (curve == MSM_AMD_BLS12381 && group == 2) {
+        using P = Bls12381Fp;
+        return in_curve_t<Fp2<P>>(ctx, Fp2<P>{fp_from<P>(P::B2_0), fp_from<P>(P::B2_1)}, flags, points, n, out_flags);
+    }
+    if (curve == MSM_AMD_BN128 && group == 2) {
+        using P = Bn254Fp;
+        return in_curve_t<Fp2<P>>(ctx, Fp2<P>{fp_from<P>(P::B2_0), fp_from<P>(P::B2_1)}, flags, points, n, out_flags);
+    }
+    ctx->err = "unknown curve/group";
+    return MSM_AMD_EINVAL;
 }
 
 // ---- GLV pre-pass (BLS12-381 G1 only, as the reference: build_glv.js:3) ----------------------------

@@ -67,6 +67,7 @@ def load_library(path=None):
     L.msm_amd_f_from_montgomery.argtypes = [c.c_int, vp, u32, u8p]
     for _fn in ("msm_amd_batch_to_affine", "msm_amd_batch_to_jacobian", "msm_amd_batch_lem_to_u", "msm_amd_batch_u_to_lem"):
         getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_batch_in_curve_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
     L.msm_amd_glv_preprocess.argtypes = [vp, u32, vp, vp, u32, vp, vp]
@@ -292,6 +293,14 @@ class Curve:
     def g2m_batchLEMtoU(self, aff): return self._conv("msm_amd_batch_lem_to_u", 2, aff, self.affine_bytes(2), self.affine_bytes(2))
     def g1m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 1, u, self.affine_bytes(1), self.affine_bytes(1))
     def g2m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 2, u, self.affine_bytes(2), self.affine_bytes(2))
+
+    def batch_in_curve_affine(self, group, points):
+        """g?m_inCurveAffine over a batch: list of 0/1 flags"""
+        points = bytes(points)
+        n = len(points) // self.affine_bytes(group)
+        out = ctypes.create_string_buffer(max(1, n))
+        self.eng._chk(self.eng.L.msm_amd_batch_in_curve_affine(self.eng.ctx, self.cid, group, 0, points, n, out))
+        return list(out.raw[:n])
 
     # --- GLV pre-pass (bls12381 G1 only): g1m_glv_preprocessEndomorphism ----------------------------------
     def g1m_glv_preprocessEndomorphism(self, points, scalars, n):
