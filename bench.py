@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--group", type=int, default=1)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-buffers", action="store_true", help="pass host memory each call (PCIe-inclusive rate; informational, never the headline value)")
+    ap.add_argument("--resident-bases", action="store_true", help="with --host-buffers: keep the bases on the GPU, copy only the scalars")
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
     args = ap.parse_args()
 
@@ -98,7 +100,15 @@ def main():
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
+    h_pts = h_sc = None
+    if args.host_buffers:
+        import numpy as np
+        h_pts = np.frombuffer(pts.download(n * C.affine_bytes(g)), dtype=np.uint8).copy()
+        h_sc = np.ascontiguousarray(sc_host)
+
     def step():
+        if args.host_buffers:
+            return C._multiexp(g, 0, pts if args.resident_bases else h_pts, h_sc, 32, n)
         if world == 1:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
         # windows sharded over the ranks; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
@@ -119,7 +129,7 @@ def main():
         for k, v in eng.timings().items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
 
-    pipelined = not args.no_pipeline
+    pipelined = not args.no_pipeline and not args.host_buffers
     # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
     # windows are sharded the accumulation per rank shrinks but the reduction latency does not, so more are needed
     depth = 1 if not pipelined else (2 if world <= 2 else 4)
@@ -186,7 +196,7 @@ def main():
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)" if args.curve == "bls12381" else "u32 limbs (254-bit Montgomery integers)",
-            "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); inputs resident in HBM",
+            "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); " + ("inputs in HOST memory, copied over PCIe inside every call" if args.host_buffers else "inputs resident in HBM"),
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,

@@ -47,7 +47,9 @@ enum { MSM_AMD_BLS12381 = 0, MSM_AMD_BN128 = 1 };
 /* flags */
 enum {
     MSM_AMD_BASES_JACOBIAN = 1, /* bases are X||Y||Z (g?m_multiexp); default affine x||y (g?m_multiexpAffine) */
-    MSM_AMD_DEVICE_PTRS = 2     /* bases and scalars already live in this context's GPU memory              */
+    MSM_AMD_DEVICE_PTRS = 2,    /* bases and scalars already live in this context's GPU memory              */
+    MSM_AMD_DEVICE_BASES = 4    /* only the bases are resident on the GPU (msm_amd_dev_alloc + msm_amd_h2d once: the fixed
+                                   SRS of a prover); the scalars are a host buffer copied over PCIe by every call    */
 };
 
 /* error codes */

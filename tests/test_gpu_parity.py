@@ -272,6 +272,21 @@ def test_split_window_groups(eng, orc):
         eng.set_option("split", 0)
 
 
+def test_resident_bases_host_scalars(eng, orc):
+    """MSM_AMD_DEVICE_BASES: the bases stay on the GPU across calls (a prover's fixed SRS), scalars come from the host."""
+    curve, group, n = "bn128", 1, 3000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, s1 = gu.random_case(curve, group, "gpu:resident:1", n)
+    _, s2 = gu.random_case(curve, group, "gpu:resident:2", n)
+    dev = eng.alloc(len(bases)).upload(bases)
+    try:
+        for sc in (s1, s2):
+            assert C.g1m_multiexpAffine(dev, sc, 32, n) == O.normalize(O.multiexp_affine(bases, sc, 32, n))
+    finally:
+        dev.free()
+
+
 def test_error_codes(eng):
     import msm_amd
     C = eng.curve("bls12381")

@@ -831,26 +831,30 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool dev_ptrs = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const bool dev_bases = dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
     const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
     const size_t base_bytes = (size_t)a.n * (jac ? JSZ : ASZ);
     const size_t scalar_bytes = (size_t)a.n * a.scalar_size;
 
     const uint8_t* d_bases;
     const uint8_t* d_scalars;
-    if (dev_ptrs) {
+    if (dev_bases) {
         if (((uintptr_t)a.bases & 15) != 0) {
             ctx->err = "device bases pointer must be 16-byte aligned";
             return MSM_AMD_EINVAL;
         }
         d_bases = (const uint8_t*)a.bases;
-        d_scalars = (const uint8_t*)a.scalars;
     } else {
         if (int rc = ensure(ctx, sl->d_bases, base_bytes)) return rc;
-        if (int rc = ensure(ctx, sl->d_scalars, scalar_bytes + 8)) return rc;
         HIPCHK(ctx, hipMemcpyAsync(sl->d_bases.p, a.bases, base_bytes, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(sl->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
         d_bases = (const uint8_t*)sl->d_bases.p;
+    }
+    if (dev_scalars) {
+        d_scalars = (const uint8_t*)a.scalars;
+    } else {
+        if (int rc = ensure(ctx, sl->d_scalars, scalar_bytes + 8)) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(sl->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
         d_scalars = (const uint8_t*)sl->d_scalars.p;
     }
 

@@ -36,6 +36,9 @@ static int (*p_eq)(int, int, const uint8_t *, const uint8_t *);
 static int (*p_combine)(int, int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_to_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
+static int (*p_dev_alloc)(msm_amd_ctx *, size_t, void **);
+static int (*p_dev_free)(msm_amd_ctx *, void *);
+static int (*p_h2d)(msm_amd_ctx *, void *, const void *, size_t);
 static int (*p_conv[4])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
@@ -71,6 +74,9 @@ static const char *load_engine(void) {
     SYM(p_combine, "msm_amd_combine")
     SYM(p_f_to_m, "msm_amd_f_to_montgomery")
     SYM(p_f_from_m, "msm_amd_f_from_montgomery")
+    SYM(p_dev_alloc, "msm_amd_dev_alloc")
+    SYM(p_dev_free, "msm_amd_dev_free")
+    SYM(p_h2d, "msm_amd_h2d")
     SYM(p_conv[0], "msm_amd_batch_to_affine")
     SYM(p_conv[1], "msm_amd_batch_to_jacobian")
     SYM(p_conv[2], "msm_amd_batch_lem_to_u")
@@ -383,6 +389,81 @@ static napi_value js_mont(napi_env env, napi_callback_info info, int to) {
 static napi_value js_to_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 1); }
 static napi_value js_from_mont(napi_env env, napi_callback_info info) { return js_mont(env, info, 0); }
 
+/* ---- resident bases: uploadBases(ctx, Uint8Array) -> handle ; multiexpResident(ctx, curve, group, flags, handle, scalars, scalarSize, n)
+ *      A prover's SRS is uploaded once; each call then moves only the scalars over PCIe (MSM_AMD_DEVICE_BASES). -------- */
+typedef struct {
+    msm_amd_ctx *ctx;
+    void *dev;
+    size_t bytes;
+} bases_t;
+static void bases_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    bases_t *b = (bases_t *)data;
+    if (b) {
+        if (b->dev && p_dev_free) p_dev_free(b->ctx, b->dev);
+        free(b);
+    }
+}
+static napi_value js_upload_bases(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    const uint8_t *p;
+    size_t lp;
+    if (argc < 2 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_bytes(env, argv[1], &p, &lp) || lp == 0) {
+        napi_throw_type_error(env, NULL, "uploadBases(ctx, bases: Uint8Array)");
+        return NULL;
+    }
+    bases_t *b = (bases_t *)calloc(1, sizeof *b);
+    if (!b) return NULL;
+    b->ctx = (msm_amd_ctx *)ctx;
+    b->bytes = lp;
+    if (p_dev_alloc(b->ctx, lp, &b->dev) || p_h2d(b->ctx, b->dev, p, lp)) {
+        napi_throw_error(env, "MSM_AMD_ERROR", p_last_error(b->ctx));
+        if (b->dev) p_dev_free(b->ctx, b->dev);
+        free(b);
+        return NULL;
+    }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, b, bases_finalize, NULL, &ext));
+    return ext;
+}
+static napi_value js_multiexp_resident(napi_env env, napi_callback_info info) {
+    size_t argc = 8;
+    napi_value argv[8];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx, *hb;
+    int curve, group;
+    uint32_t flags, ss, n;
+    const uint8_t *sc;
+    size_t ls;
+    if (argc < 8 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &curve) || get_i32(env, argv[2], &group) ||
+        get_u32(env, argv[3], &flags) || napi_get_value_external(env, argv[4], &hb) != napi_ok || get_bytes(env, argv[5], &sc, &ls) ||
+        get_u32(env, argv[6], &ss) || get_u32(env, argv[7], &n) || (curve != 0 && curve != 1) || (group != 1 && group != 2)) {
+        napi_throw_type_error(env, NULL, "multiexpResident(ctx, curve, group, flags, basesHandle, scalars: Uint8Array, scalarSize, n)");
+        return NULL;
+    }
+    bases_t *b = (bases_t *)hb;
+    flags &= MSM_AMD_BASES_JACOBIAN;
+    size_t stride = (size_t)((flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * n8_of(curve) * group;
+    if (b->bytes < (size_t)n * stride || ls < (size_t)n * ss) {
+        napi_throw_range_error(env, NULL, "resident bases / scalars shorter than n elements");
+        return NULL;
+    }
+    call_t c;
+    memset(&c, 0, sizeof c);
+    c.curve = curve;
+    c.group = group;
+    int rc = p_multiexp((msm_amd_ctx *)ctx, curve, group, flags | MSM_AMD_DEVICE_BASES, b->dev, sc, ss, n, c.out);
+    if (rc) {
+        napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+        return NULL;
+    }
+    return make_result(env, &c);
+}
+
 /* ---- batch conversions: batchConvert(ctx, which, curve, group, bytes) -> bytes
  *      which: 0 batchToAffine, 1 batchToJacobian, 2 batchLEMtoU, 3 batchUtoLEM ---------------------------- */
 static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
@@ -513,6 +594,8 @@ static napi_value init(napi_env env, napi_value exports) {
         {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
         {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"uploadBases", NULL, js_upload_bases, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpResident", NULL, js_multiexp_resident, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -112,6 +112,12 @@ function curve(curveName, opts) {
         };
         return {
             F: { n8: fsz },
+            // a prover's fixed bases (SRS): upload once, then only the scalars cross PCIe on every call
+            uploadBases: (buffBases) => ({ handle: native.uploadBases(ctx, buffBases), n: Math.floor(buffBases.byteLength / (2 * fsz)), jacobian: false }),
+            multiExpResident: async (bases, buffScalars) => {
+                const scalarSize = Math.floor(buffScalars.byteLength / bases.n);
+                return native.multiexpResident(ctx, C.id, g, 0, bases.handle, buffScalars, scalarSize, bases.n);
+            },
             multiExp: run(FLAG_JACOBIAN, 3 * fsz),
             multiExpAffine: run(0, 2 * fsz),
             // buffer-in / buffer-out forms of the batch conversions (ffjavascript exposes them under these names)

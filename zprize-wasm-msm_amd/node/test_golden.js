@@ -80,6 +80,12 @@ async function main() {
                     if (gc !== canon(ch.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id} chunk ${ch.start_bit}/${ch.chunk_size} differs`);
                     checked++;
                 }
+                // resident bases: upload once, scalars from the host
+                if (affine && rec.n > 0 && rec.scalar_size * rec.n === scalars.length) {
+                    const h = Gx.uploadBases(bases);
+                    const outR = await Gx.multiExpResident(h, scalars);
+                    if (Buffer.from(outR).toString("hex") !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: resident-bases result differs`);
+                }
                 // surface 2: async, buffers in / Uint8Array out
                 if (rec.n > 0 && rec.scalar_size * rec.n === scalars.length) {
                     const out = await (affine ? Gx.multiExpAffine(bases, scalars) : Gx.multiExp(bases, scalars));

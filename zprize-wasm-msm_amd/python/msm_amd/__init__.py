@@ -25,6 +25,7 @@ N8 = {"bls12381": 48, "bn128": 32}
 
 FLAG_JACOBIAN = 1
 FLAG_DEVICE = 2
+FLAG_DEVICE_BASES = 4
 
 
 class MsmAmdError(RuntimeError):
@@ -206,10 +207,10 @@ class Curve:
     def _multiexp(self, group, flags, bases, scalars, scalar_size, n):
         pb, dev_b, kb = _as_ptr(bases)
         ps, dev_s, ks = _as_ptr(scalars)
-        if dev_b != dev_s:
-            raise MsmAmdError("bases and scalars must both be host or both be device buffers")
+        if dev_s and not dev_b:
+            raise MsmAmdError("device scalars with host bases is not supported")
         if dev_b:
-            flags |= FLAG_DEVICE
+            flags |= FLAG_DEVICE if dev_s else FLAG_DEVICE_BASES     # resident bases, scalars from the host each call
         out = ctypes.create_string_buffer(self.jacobian_bytes(group))
         self.eng._chk(self.eng.L.msm_amd_multiexp(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, out))
         return out.raw
