@@ -4,6 +4,7 @@
 // launcher declarations.
 #pragma once
 #include "engine_common.hpp"
+#include "curve_u.hpp"
 
 namespace msm {
 
@@ -21,16 +22,24 @@ struct TailCtl {
     uint32_t pad[2];
 };
 
+// Buckets are held in the unsaturated representation of field_u.hpp / curve_u.hpp (BU<F>); bases arrive in
+// the packed image of the reference and are re-sliced on load (no arithmetic).
 template <class F>
-MSM_D XYZZ<F> accumulate_span(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t first, uint32_t len) {
-    XYZZ<F> acc = XYZZ<F>::inf();
+using BU = XYZZU<typename UKind<F>::type>;
+
+template <class F>
+MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t first, uint32_t len) {
+    using K = typename UKind<F>::type;
+    BU<F> acc = BU<F>::inf();
     for (uint32_t k = 0; k < len; ++k) {
         uint32_t e = sorted[first + k];
         uint32_t idx = e & 0x7fffffffu;
         Affine<F> p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
-        bool inf = p.is_inf();
-        p.y = F::cneg(p.y, (e >> 31) != 0 && !inf);
-        XYZZ<F>::madd(acc, p.x, p.y);
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
+        if (words_all_zero(w, 2 * K::WORDS)) continue;   // affine infinity (build_curve_jacobian_a0.js:124-171)
+        auto x2 = K::load(w);
+        auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
+        BU<F>::madd(acc, x2, y2);
     }
     return acc;
 }
@@ -45,8 +54,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ 
     uint32_t b = order[r];
     uint32_t cnt = count[b];
     uint32_t off = offset[b];
-    XYZZ<F> acc = accumulate_span<F>(bases, sorted, off, min(cnt, seg));
-    store16(buckets + (size_t)b * sizeof(XYZZ<F>), acc);
+    BU<F> acc = accumulate_span<F>(bases, sorted, off, min(cnt, seg));
+    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
     if (cnt > seg) {
         uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
         uint32_t base = atomicAdd(&ctl->nwork, extra);
@@ -65,8 +74,8 @@ __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restri
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < nwork; item += gridDim.x * blockDim.x) {
         uint2 w = work[item];
         uint32_t len = min(seg, count[w.x] - w.y);
-        XYZZ<F> acc = accumulate_span<F>(bases, sorted, offset[w.x] + w.y, len);
-        store16(seg_out + (size_t)item * sizeof(XYZZ<F>), acc);
+        BU<F> acc = accumulate_span<F>(bases, sorted, offset[w.x] + w.y, len);
+        store16(seg_out + (size_t)item * sizeof(BU<F>), acc);
     }
 }
 
@@ -74,26 +83,26 @@ template <class F>
 __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict__ ctl, const uint4* __restrict__ biglist,
                                                        const uint8_t* __restrict__ seg_out, uint8_t* __restrict__ buckets) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
     const uint32_t nbig = ctl->nbig;
     for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         uint4 d = biglist[bi];   // bucket, first segment, number of segments
-        XYZZ<F> loc = XYZZ<F>::inf();
+        BU<F> loc = BU<F>::inf();
         for (uint32_t j = threadIdx.x; j < d.z; j += blockDim.x)
-            loc = XYZZ<F>::add_ni(loc, load16<XYZZ<F>>(seg_out + (size_t)(d.y + j) * sizeof(XYZZ<F>)));
+            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + (size_t)(d.y + j) * sizeof(BU<F>)));
         sh[threadIdx.x] = loc;
         __syncthreads();
         for (int s = blockDim.x / 2; s > 0; s >>= 1) {
             if ((int)threadIdx.x < s) {
-                XYZZ<F> a = sh[threadIdx.x];
-                XYZZ<F> bb = sh[threadIdx.x + s];
-                sh[threadIdx.x] = XYZZ<F>::add_ni(a, bb);
+                BU<F> a = sh[threadIdx.x];
+                BU<F> bb = sh[threadIdx.x + s];
+                sh[threadIdx.x] = BU<F>::add_ni(a, bb);
             }
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            XYZZ<F> cur = load16<XYZZ<F>>(buckets + (size_t)d.x * sizeof(XYZZ<F>));
-            store16(buckets + (size_t)d.x * sizeof(XYZZ<F>), XYZZ<F>::add_ni(cur, sh[0]));
+            BU<F> cur = load16<BU<F>>(buckets + (size_t)d.x * sizeof(BU<F>));
+            store16(buckets + (size_t)d.x * sizeof(BU<F>), BU<F>::add_ni(cur, sh[0]));
         }
         __syncthreads();
     }
@@ -117,38 +126,38 @@ struct InlineAdds<Fp<P, true>> {
     static constexpr bool value = true;
 };
 template <class F>
-MSM_D XYZZ<F> radd(const XYZZ<F>& a, const XYZZ<F>& b) {
-    if constexpr (InlineAdds<F>::value) return XYZZ<F>::add(a, b);
-    else return XYZZ<F>::add_ni(a, b);
+MSM_D BU<F> radd(const BU<F>& a, const BU<F>& b) {
+    if constexpr (InlineAdds<F>::value) return BU<F>::add(a, b);
+    else return BU<F>::add_ni(a, b);
 }
 template <class F>
-MSM_D XYZZ<F> rdbl(const XYZZ<F>& a) {
-    if constexpr (InlineAdds<F>::value) return XYZZ<F>::dbl(a);
-    else return XYZZ<F>::dbl_ni(a);
+MSM_D BU<F> rdbl(const BU<F>& a) {
+    if constexpr (InlineAdds<F>::value) return BU<F>::dbl(a);
+    else return BU<F>::dbl_ni(a);
 }
 
 template <class F>
 __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
                                                         uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    XYZZ<F>* sh = reinterpret_cast<XYZZ<F>*>(smem);
+    BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
     uint32_t w = blockIdx.x / wgs_per_window;
     uint32_t wg = blockIdx.x % wgs_per_window;
     uint32_t t = wg * blockDim.x + threadIdx.x;
-    XYZZ<F> res = XYZZ<F>::inf();
+    BU<F> res = BU<F>::inf();
     if (t < lanes_per_window) {
         uint32_t base = t * L;
-        XYZZ<F> run = XYZZ<F>::inf();
-        XYZZ<F> sum = XYZZ<F>::inf();
+        BU<F> run = BU<F>::inf();
+        BU<F> sum = BU<F>::inf();
         for (int j = (int)L - 1; j >= 0; --j) {
             if (base + j < half) {
-                XYZZ<F> bk = load16<XYZZ<F>>(buckets + ((size_t)w * half + base + j) * sizeof(XYZZ<F>));
+                BU<F> bk = load16<BU<F>>(buckets + ((size_t)w * half + base + j) * sizeof(BU<F>));
                 run = radd<F>(run, bk);
             }
             sum = radd<F>(sum, run);
         }
         // res = sum + base * run
-        XYZZ<F> m = XYZZ<F>::inf();
+        BU<F> m = BU<F>::inf();
         if (base != 0) {
             int top = 31 - __clz(base);
             for (int bit = top; bit >= 0; --bit) {
@@ -162,13 +171,14 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
     __syncthreads();
     for (int d = blockDim.x / 2; d > 0; d >>= 1) {
         if ((int)threadIdx.x < d) {
-            XYZZ<F> a = sh[threadIdx.x];
-            XYZZ<F> bb = sh[threadIdx.x + d];
+            BU<F> a = sh[threadIdx.x];
+            BU<F> bb = sh[threadIdx.x + d];
             sh[threadIdx.x] = radd<F>(a, bb);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store16(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>), XYZZ<F>::canon(sh[0]));   // leaves the GPU: canonical
+    // leaves the GPU: back to the canonical packed image XYZZ<F> that the host combine reads
+    if (threadIdx.x == 0) sh[0].to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
 }
 
 
@@ -179,17 +189,24 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sor
     k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
                                                        (uint4*)biglist);
     k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
-    k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(XYZZ<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
+    k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials) {
-    k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * sizeof(XYZZ<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials);
+    k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials);
+}
+
+// bytes of one bucket in HBM (the engine sizes its bucket arrays and LDS tiles with this)
+template <class F>
+size_t bucket_bytes() {
+    return sizeof(BU<F>);
 }
 
 #define MSM_INSTANTIATE_BUCKET_KERNELS(F)                                                                                                   \
     template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,   \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*, uint8_t*, uint32_t);                              \
-    template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*);
+    template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
+    template size_t bucket_bytes<F>();
 
 }  // namespace msm

@@ -45,6 +45,8 @@ void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, cons
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials);
 // field flavour used inside the bucket kernels: G1 fields expand their multiplies inline
 template <class F>
+size_t bucket_bytes();   // bytes of one bucket in HBM (the bucket kernels keep their own representation, curve_u.hpp)
+template <class F>
 struct KernelField {
     using type = F;
 };
@@ -821,7 +823,9 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out);
 template <class F>
 static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     using X = XYZZ<F>;
-    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);
+    using FK = typename KernelField<F>::type;
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);   // packed images
+    const size_t BSZ = bucket_bytes<FK>();                                               // one bucket in HBM
     sl->trivial = false;
     sl->raw_out = a.raw_out;
     sl->finish = &finish_msm<F>;
@@ -902,7 +906,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * XSZ)) return rc;
+    if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
     uint32_t* count = (uint32_t*)sl->d_count.p;
     uint32_t* offset = (uint32_t*)sl->d_offset.p;
     uint32_t* cursor = (uint32_t*)sl->d_cursor.p;
@@ -981,7 +985,6 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
     // ---- 4. accumulate
-    using FK = typename KernelField<F>::type;
     // segment length: 2x the mean bucket population, at least 32 (a Poisson bucket practically never exceeds it);
     // longer buckets -- adversarial scalars, or the few buckets of a narrow top window when the scalar width is
     // not a multiple of c -- are cut into segments, which bounds the longest dependent chain of additions
@@ -990,10 +993,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
-    if (int rc = ensure(ctx, sl->d_segout, max_segs * XSZ)) return rc;
+    if (int rc = ensure(ctx, sl->d_segout, max_segs * BSZ)) return rc;
     HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
     uint32_t tail_block = 256;
-    while ((size_t)tail_block * XSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
+    while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
     uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
     launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                           (uint8_t*)sl->d_segout.p, tail_block);
@@ -1017,7 +1020,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         p.L = ctx->force_L ? ctx->force_L : std::min(others_pending ? 16u : 8u, std::max(1u, (nbuckets + 65535u) / 65536u));
         p.lanes = (g.half + p.L - 1) / p.L;
         p.rblock = std::min(256u, std::max(64u, p.lanes));
-        while ((size_t)p.rblock * XSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
+        while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
         p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
         return p;
     };
@@ -1043,7 +1046,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (nparts1) {
         hipStream_t sc = sl->stream_c;
         HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
-        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * XSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ);
+        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * BSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ);
         HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
         HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
     }
