@@ -71,7 +71,7 @@ static int run(const char* name) {
         (void)mode;
     }
     // chains of mixed additions with signs, including repeats (doubling) and opposite points
-    for (int trial = 0; trial < 40; ++trial) {
+    for (int trial = 0; trial < 200; ++trial) {
         UX ua = UX::inf();
         HX ha = HX::inf();
         int len = 1 + (int)(rng() % 24);

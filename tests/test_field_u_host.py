@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_field_u_against_host_field(tmp_path):
     exe = tmp_path / "test_field_u"
-    subprocess.run(["hipcc", "--cuda-host-only", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "zprize-wasm-msm_amd", "csrc"),
+    subprocess.run(["hipcc", "--cuda-host-only", "-O0", "-std=c++17", "-I", os.path.join(ROOT, "zprize-wasm-msm_amd", "csrc"),
                     os.path.join(ROOT, "tests", "host", "test_field_u.hip"), "-o", str(exe)], check=True, timeout=600)
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
