@@ -57,8 +57,10 @@ def main():
     ap.add_argument("--group", type=int, default=1)
     ap.add_argument("--window-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (msm_amd_set_option), e.g. reduce_l=32; for experiments")
     ap.add_argument("--host-buffers", action="store_true", help="pass host memory each call (PCIe-inclusive rate; informational, never the headline value)")
     ap.add_argument("--resident-bases", action="store_true", help="with --host-buffers: keep the bases on the GPU, copy only the scalars")
+    ap.add_argument("--depth", type=int, default=0, help="calls in flight when pipelined (default 2; 4 for more than two ranks)")
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
     args = ap.parse_args()
 
@@ -132,8 +134,11 @@ def main():
     pipelined = not args.no_pipeline and not args.host_buffers
     # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
     # windows are sharded the accumulation per rank shrinks but the reduction latency does not, so more are needed
-    depth = 1 if not pipelined else (2 if world <= 2 else 4)
+    depth = 1 if not pipelined else (args.depth or (2 if world <= 2 else 4))
     eng.set_option("slots", max(depth, 1))
+    for kv in args.opt:
+        name, val = kv.split("=")
+        eng.set_option(name, int(val))
 
     def finish(ticket):
         out = ticket.wait()

@@ -44,8 +44,28 @@ MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint32_t* _
     return acc;
 }
 
+// Full additions inside the reduction: expanded inline for the G1 fields (the kernel runs one wave per
+// SIMD and is latency-bound; calls would spill the three live points around every addition), out of
+// line for Fp2 where the inlined body would be ~3x larger.
 template <class F>
-__global__ void __launch_bounds__(256) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+struct InlineAdds {
+    static constexpr bool value = false;
+};
+template <class P>
+struct InlineAdds<Fp<P, true>> {
+    static constexpr bool value = true;
+};
+// Occupancy target of the accumulation (waves per SIMD): 3 for G1 -- the kernel needs 165 VGPRs, three waves keep the
+// v_mad_u64_u32 pipe fed through the point loads; the Fp2 kernels need all 512 registers of a SIMD lane pair.
+#ifndef MSM_ACC_WAVES
+#define MSM_ACC_WAVES 3
+#endif
+template <class F>
+struct AccWaves {
+    static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : 1;
+};
+template <class F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
                                                      TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
@@ -114,17 +134,6 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
 // A = sum_j B[t*L+j]; adding (t*L)*A (double-and-add) makes the lane's share exact; a workgroup
 // tree in LDS then leaves one partial per workgroup.
 // ------------------------------------------------------------------------------------------
-// Full additions inside the reduction: expanded inline for the G1 fields (the kernel runs one wave per
-// SIMD and is latency-bound; calls would spill the three live points around every addition), out of
-// line for Fp2 where the inlined body would be ~3x larger.
-template <class F>
-struct InlineAdds {
-    static constexpr bool value = false;
-};
-template <class P>
-struct InlineAdds<Fp<P, true>> {
-    static constexpr bool value = true;
-};
 template <class F>
 MSM_D BU<F> radd(const BU<F>& a, const BU<F>& b) {
     if constexpr (InlineAdds<F>::value) return BU<F>::add(a, b);

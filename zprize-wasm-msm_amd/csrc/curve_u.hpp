@@ -71,6 +71,7 @@ struct UG1 {
     using Y = FuM<P, 3>;                       // stored y: always a Montgomery output
     using M = FuM<P, 3>;                       // stored zz, zzz
     static constexpr int WORDS = P::N;         // packed words per coordinate
+    static constexpr bool INLINE_RARE = true;
     MSM_HD static In load(const uint32_t* w) { return u_from_packed<P>(w); }
     template <class T>
     MSM_HD static void store(uint32_t* w, const T& a) { u_to_packed(w, a); }
@@ -97,6 +98,7 @@ struct UG2 {
     using Y = Fp2u<Fu<P, UC<P>::MASK + 31, 16>>;   // a normalised lazy difference of two products
     using M = Fp2u<FuM<P, 3>>;
     static constexpr int WORDS = 2 * P::N;
+    static constexpr bool INLINE_RARE = false;
     MSM_HD static In load(const uint32_t* w) { return {u_from_packed<P>(w), u_from_packed<P>(w + P::N)}; }
     template <class T>
     MSM_HD static void store(uint32_t* w, const T& a) {
@@ -145,9 +147,15 @@ struct XYZZU {
     }
     MSM_HD bool is_inf() const { return fis_zero(zz); }
 
-    // 2*(x, y), affine and finite (mdbl-2008-s-1).  Rare on the hot path: out of line.
+    // 2*(x, y), affine and finite (mdbl-2008-s-1).  Rare on the hot path.  G1 expands it inline: a callee's register
+    // allocation is not governed by the kernel's occupancy target, and as a call it pinned k_accumulate at 200 VGPRs
+    // (2 waves/SIMD); inline the kernel needs 165 (3 waves).  G2 keeps it out of line (code size).
     template <class X2, class Y2>
     __host__ __device__ __noinline__ static XYZZU dbl_affine(X2 x_in, Y2 y_in) {
+        return dbl_affine_inl(x_in, y_in);
+    }
+    template <class X2, class Y2>
+    MSM_HD static XYZZU dbl_affine_inl(const X2& x_in, const Y2& y_in) {
         auto one = K::one();
         auto x = fmul(x_in, one);   // brings the value bound of a loaded coordinate down to a product's
         auto y = fmul(y_in, one);
@@ -188,7 +196,8 @@ struct XYZZU {
         auto PP = fsqr(Pd);
         auto RR = fsqr(Rd);
         if (fis_zero(PP) && fis_zero(RR)) {   // same point: P = R = 0
-            acc = dbl_affine(x2, y2);
+            if constexpr (K::INLINE_RARE) acc = dbl_affine_inl(x2, y2);
+            else acc = dbl_affine(x2, y2);
             return;
         }
         auto PPP = fmul(Pd, PP);

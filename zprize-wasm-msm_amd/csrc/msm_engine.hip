@@ -697,7 +697,7 @@ struct Slot {
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
-    hipEvent_t ev[9] = {};        // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency)
+    hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts
     hipStream_t stream_b = nullptr;   // B: this slot's bucket reduction + partials to host
     hipStream_t stream_c = nullptr;   // C: reduction of the second window group when a lone call is split in two
     hipEvent_t ev_c = nullptr;        // second group's reduction done
@@ -715,7 +715,8 @@ struct Slot {
 
 struct msm_amd_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;     // A: transfers, sort, accumulation
+    hipStream_t stream = nullptr;     // A: bucket accumulation (the ALU-bound stage), in call order
+    hipStream_t stream_s = nullptr;   // S: transfers + bucket sort of the NEXT call, under the current call's accumulation
     static constexpr uint32_t MAX_SLOTS = 4;
     Slot slots[MAX_SLOTS];
     uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..4)
@@ -834,7 +835,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         return 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream_s;   // everything up to the sorted index lists runs on stream S
     const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
     const bool dev_bases = dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
     const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
@@ -984,7 +985,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
-    // ---- 4. accumulate
+    // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation)
+    st = ctx->stream;
+    HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
+    HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
     // segment length: 2x the mean bucket population, at least 32 (a Poisson bucket practically never exceeds it);
     // longer buckets -- adversarial scalars, or the few buckets of a narrow top window when the scalar width is
     // not a multiple of c -- are cut into segments, which bounds the longest dependent chain of additions
@@ -1009,15 +1013,20 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
     // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
     hipStream_t sb = sl->stream_b;
-    // buckets per lane: 8 when every window is owned (throughput), fewer when few windows are reduced at once (latency),
-    // 16 when another call is already in flight: its latency is hidden behind that call's accumulation, and fewer,
-    // longer lanes cost less SIMD time (profiles: 3.99 -> 3.91 ms per pipelined call at n = 2^20)
+    // buckets per lane: up to 8 for a lone call (its reduction is on the critical path: short dependent chains, one wave on
+    // every SIMD); 32 when another call is already in flight: the reduction then hides behind that call's accumulation, and
+    // what counts is its SIMD time and its register footprint -- fewer, longer lanes issue fewer instructions in total
+    // (the double-and-add by the lane's first index is paid once per lane) and leave 3/4 of the SIMDs to the
+    // accumulation waves alone (n = 2^20, two calls in flight: 3.43 ms per call with L = 8, 3.09 ms with L = 32,
+    // 3.21 ms with L = 64 where the reduction outlasts the accumulation it hides behind)
     struct Plan {
         uint32_t L, lanes, rblock, wgs;
     };
     auto plan = [&](uint32_t nbuckets) {
         Plan p;
-        p.L = ctx->force_L ? ctx->force_L : std::min(others_pending ? 16u : 8u, std::max(1u, (nbuckets + 65535u) / 65536u));
+        p.L = ctx->force_L ? ctx->force_L
+                           : others_pending ? std::min(32u, std::max(1u, g.half / 1024u))
+                                            : std::min(8u, std::max(1u, (nbuckets + 65535u) / 65536u));
         p.lanes = (g.half + p.L - 1) / p.L;
         p.rblock = std::min(256u, std::max(64u, p.lanes));
         while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
@@ -1117,7 +1126,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     (void)hipEventElapsedTime(&ms, sl->ev[1], sl->ev[2]); ctx->timings[1] = ms;
     (void)hipEventElapsedTime(&ms, sl->ev[2], sl->ev[3]); ctx->timings[2] = ms;
     (void)hipEventElapsedTime(&ms, sl->ev[3], sl->ev[4]); ctx->timings[3] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[4], sl->ev[5]); ctx->timings[4] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[9], sl->ev[5]); ctx->timings[4] = ms;
     (void)hipEventElapsedTime(&ms, sl->ev[5], sl->ev[6]); ctx->timings[5] = ms;
     ctx->timings[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
     (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]); ctx->timings[7] = ms;
@@ -1171,6 +1180,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
     }
     if (rc) {
         // leave the streams clean so the context stays usable
+        (void)hipStreamSynchronize(ctx->stream_s);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(sl->stream_b);
         return rc;
@@ -1350,7 +1360,8 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return MSM_AMD_EHIP;
     }
@@ -1373,6 +1384,7 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
 void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
     (void)hipStreamSynchronize(ctx->stream);
     for (Slot& sl : ctx->slots) {
         if (sl.stream_b) {
@@ -1390,6 +1402,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
         for (auto& e : sl.ev)
             if (e) (void)hipEventDestroy(e);
     }
+    if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
