@@ -157,6 +157,12 @@ int msm_amd_glv_endomorphism(const uint8_t *point_affine, uint32_t sign, uint8_t
 int msm_amd_glv_preprocess(msm_amd_ctx *ctx, uint32_t flags, const void *points, const void *scalars, uint32_t n,
                            void *points_out, void *scalars_out);
 
+/* The split the engine itself applies inside BLS12-381 G1 MSMs (not a reference export; exposed so that it can be
+ * checked without a GPU): k == s * (k1 + k2*lambda) (mod r), |k1|, k2 < 2^127.  out32 = |k1| (16 bytes LE) || k2 (16 bytes);
+ * *sign bit 0 = the P term is negative, bit 1 = the phi(P) term is negative.  Host only.  Option "glv"
+ * (msm_amd_set_option): 0 = never split, 1 = where it pays (default: n <= 2^17), 2 = whenever it applies.      */
+int msm_amd_glv_split(const uint8_t *scalar32, uint8_t *out32, uint32_t *sign);
+
 /* ---- device memory + measurement utilities (bench / tests) ------------------------------------- */
 int msm_amd_dev_alloc(msm_amd_ctx *ctx, size_t bytes, void **dev_ptr);
 int msm_amd_dev_free(msm_amd_ctx *ctx, void *dev_ptr);

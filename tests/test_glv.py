@@ -52,6 +52,21 @@ def test_host_decompose_and_endomorphism_match_oracle(oracle_lib):
     assert msm_amd.glv_endomorphism(pts[:96], 1) == lamP
 
 
+def test_engine_split_identity_and_bounds():
+    """The split the engine applies inside BLS12-381 G1 MSMs: k == +-|k1| +- k2*lambda (mod r), both halves below 2^127
+    (so that their signed radix-2^16 digits never carry out of the eighth window)."""
+    import msm_amd
+    from oracle import glv
+    r = glv.R
+    extra = [(r - 1) // 2, (r + 1) // 2, glv.LAMBDA - 1, glv.LAMBDA, glv.LAMBDA + 1, glv.LAMBDA // 2, glv.LAMBDA // 2 + 1, r - glv.LAMBDA]
+    for kk in _edge_scalars() + extra:
+        a, b, s = msm_amd.glv_split(kk.to_bytes(32, "little"))
+        assert a < (1 << 127) and b < (1 << 127), hex(kk)
+        s1 = -a if s & 1 else a
+        s2 = -b if s & 2 else b
+        assert (s1 + s2 * glv.LAMBDA - kk) % r == 0, hex(kk)
+
+
 @pytest.mark.gpu
 def test_gpu_preprocess_matches_oracle_and_preserves_the_msm(oracle_lib):
     """g1m_glv_preprocessEndomorphism on the GPU == the oracle's, byte for byte; and the MSM of the 2n preprocessed

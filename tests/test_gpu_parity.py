@@ -272,6 +272,33 @@ def test_split_window_groups(eng, orc):
         eng.set_option("split", 0)
 
 
+def test_glv_path_matches_oracle_and_plain_path(eng, orc):
+    """BLS12-381 G1 with whole 32-byte scalars and c = 16 runs through the engine's GLV split (2n virtual points, 8 windows):
+    same bytes as the oracle and as the plain 16-window path, including scalars >= r, around r/2, 0, 1 and an affine infinity."""
+    curve, group, n = "bls12381", 1, 4500
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    r = gu.R_ORDER[curve]
+    bases, scalars = gu.random_case(curve, group, "gpu:glvpath", n)
+    u0 = 0xac45a4010001a4020000000100000000
+    edge = [0, 1, 2, r - 1, r, r + 1, 2 * r + 7, (1 << 256) - 1, 1 << 255, (r - 1) // 2, (r + 1) // 2, (1 << 128) - 1, 1 << 127,
+            u0 // 2, u0, u0 + 1, r - u0, 0x8000, 0x80008000, r - 0x8000, u0 - 0x8000, (0x8000 << 112) | 0x8000]   # digits equal to 2^15 under both signs
+    scalars = b"".join(v.to_bytes(32, "little") for v in edge) + scalars[32 * len(edge):]
+    bases = bases[:96 * 20] + bytes(96) + bases[96 * 21:]            # affine infinity among the inputs
+    bases = bases[:96 * 30] + bases[96 * 31:96 * 32] + bases[96 * 31:]   # a repeated point
+    expect = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    try:
+        eng.set_option("glv", 2)
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == expect
+        assert eng.geometry()["windows"] == 8
+        assert C.g1m_multiexp(O.batch_to_jacobian(bases), scalars, 32, n) == expect     # Jacobian bases: converted, then the same path
+        eng.set_option("glv", 0)
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == expect
+        assert eng.geometry()["windows"] == 17
+    finally:
+        eng.set_option("glv", 1)
+
+
 def test_resident_bases_host_scalars(eng, orc):
     """MSM_AMD_DEVICE_BASES: the bases stay on the GPU across calls (a prover's fixed SRS), scalars come from the host."""
     curve, group, n = "bn128", 1, 3000
@@ -375,6 +402,15 @@ def test_full_size_properties(eng, orc, curve, group, logn):
             acc = O.double(acc)
         acc = O.add(acc, fc(pts, ds, 32, n, 16 * w, 16))
     assert O.normalize(acc) == Rs
+    # the GLV schedule (8 windows over 2n half-length scalars) and the plain 16-window schedule agree at full size
+    if (curve, group) == ("bls12381", 1):
+        try:
+            eng.set_option("glv", 2)
+            Rg = f(pts, ds, 32, n)
+            assert eng.geometry()["windows"] == 8
+        finally:
+            eng.set_option("glv", 1)
+        assert Rg == Rs
     for b in (ds, dt, du, pts):
         b.free()
 

@@ -27,14 +27,31 @@ struct TailCtl {
 template <class F>
 using BU = XYZZU<typename UKind<F>::type>;
 
+// With xbeta != nullptr (GLV path of the engine) the index lists address 2n virtual points: item 2i is base i, item 2i+1 its
+// endomorphism image (xbeta[i], y_i).
 template <class F>
-MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted, uint32_t first, uint32_t len) {
+MSM_D Affine<F> load_point(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, uint32_t idx) {
+    Affine<F> p;
+    if (xbeta) {
+        const uint8_t* pb = bases + (size_t)(idx >> 1) * sizeof(Affine<F>);
+        const uint8_t* px = (idx & 1u) ? xbeta + (size_t)(idx >> 1) * sizeof(F) : pb;
+        p.x = load16<F>(px);
+        p.y = load16<F>(pb + sizeof(F));
+    } else {
+        p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
+    }
+    return p;
+}
+// (Requesting the point of entry k+1 before the addition of entry k was measured: no gain at 2 waves/SIMD, and at 3 waves
+// the 24 extra registers spill -- the gather latency is already covered by the other waves' ~4600 VALU instructions.)
+template <class F>
+MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted, uint32_t first,
+                            uint32_t len) {
     using K = typename UKind<F>::type;
     BU<F> acc = BU<F>::inf();
     for (uint32_t k = 0; k < len; ++k) {
-        uint32_t e = sorted[first + k];
-        uint32_t idx = e & 0x7fffffffu;
-        Affine<F> p = load16<Affine<F>>(bases + (size_t)idx * sizeof(Affine<F>));
+        const uint32_t e = sorted[first + k];
+        const Affine<F> p = load_point<F>(bases, xbeta, e & 0x7fffffffu);
         const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
         if (words_all_zero(w, 2 * K::WORDS)) continue;   // affine infinity (build_curve_jacobian_a0.js:124-171)
         auto x2 = K::load(w);
@@ -65,7 +82,7 @@ struct AccWaves {
     static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : 1;
 };
 template <class F>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
                                                      TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
@@ -74,7 +91,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
     uint32_t b = order[r];
     uint32_t cnt = count[b];
     uint32_t off = offset[b];
-    BU<F> acc = accumulate_span<F>(bases, sorted, off, min(cnt, seg));
+    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, seg));
     store16(buckets + (size_t)b * sizeof(BU<F>), acc);
     if (cnt > seg) {
         uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
@@ -86,7 +103,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
 }
 
 template <class F>
-__global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ sorted,
+__global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                           const TailCtl* __restrict__ ctl, const uint2* __restrict__ work, uint32_t seg,
                                                           uint8_t* __restrict__ seg_out) {
@@ -94,7 +111,7 @@ __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restri
     for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < nwork; item += gridDim.x * blockDim.x) {
         uint2 w = work[item];
         uint32_t len = min(seg, count[w.x] - w.y);
-        BU<F> acc = accumulate_span<F>(bases, sorted, offset[w.x] + w.y, len);
+        BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[w.x] + w.y, len);
         store16(seg_out + (size_t)item * sizeof(BU<F>), acc);
     }
 }
@@ -192,12 +209,12 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 
 
 template <class F>
-void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
                        uint32_t tail_block) {
-    k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
+    k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
                                                        (uint4*)biglist);
-    k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
+    k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
     k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
@@ -213,7 +230,7 @@ size_t bucket_bytes() {
 }
 
 #define MSM_INSTANTIATE_BUCKET_KERNELS(F)                                                                                                   \
-    template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,   \
+    template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,   \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*, uint8_t*, uint32_t);                              \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
     template size_t bucket_bytes<F>();

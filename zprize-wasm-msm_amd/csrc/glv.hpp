@@ -142,5 +142,80 @@ MSM_HD uint32_t decompose(const uint32_t* k, uint32_t* k1abs, uint32_t* k2abs) {
     return sign;
 }
 
+// ------------------------------------------------------------------------------------------
+// The engine's own split, used INSIDE the MSM (not a reference export): k == s * (k1 + k2*lambda) (mod r) with
+// |k1| < 2^127 and 0 <= k2 < 2^127, lambda = -u0 (mod r), the eigenvalue of phi(x, y) = (beta*x, y) for the
+// reference's beta (build_glv.js:15-22), so that k*P = s*(k1*P + k2*phi(P)); u0 = x^2 is the 128-bit integer the division uses.  Compared with build_glv.js's floor-based quotients the
+// residue is first centred (k > (r-1)/2 -> r - k, remembered in s) and k2 is ROUNDED, so both halves stay one bit
+// below 2^128: their signed radix-2^16 recoding then never carries out of the eighth window, and the MSM over
+// the 2n half-length scalars needs exactly 8 windows.
+//   kr = k mod r;  flip = kr > (r-1)/2;  kr = flip ? r - kr : kr
+//   t = kr + floor(u0/2);  b = floor(t / u0);  k1 = (t mod u0) - floor(u0/2);  k2 = -b          (kr = k1 + b*u0 = k1 + k2*lambda mod r)
+// Stores |k1| and b = |k2|.  Returns bit 0: the P term is negative (flip xor k1 < 0), bit 1: the phi(P) term is negative (not flip).
+struct SplitConsts {
+    static constexpr uint32_t RHALF[8] = {0x80000000u, 0x7fffffffu, 0x7fff2dffu, 0xa9ded201u, 0x04d0ec02u, 0x199cec04u, 0x94cebea4u, 0x39f6d3a9u};   // (r-1)/2
+    static constexpr uint32_t LHALF[4] = {0x80000000u, 0x00000000u, 0x8000d201u, 0x5622d200u};   // floor(u0/2)
+    static constexpr uint32_t M[9] = {0x818be409u, 0xa1a872d6u, 0x27adc027u, 0x034eb4b9u, 0xf6cfee2eu, 0x63f6e522u, 0xe01faaddu, 0x7c6becf1u, 0x00000001u};   // floor(2^384/u0)
+};
+MSM_HD uint32_t split_centered(const uint32_t* k, uint32_t* k1abs, uint32_t* k2abs) {
+    // kr = k mod r  (k < 2^256 < 3r)
+    uint32_t kr[8], tmp[8];
+    for (int i = 0; i < 8; ++i) kr[i] = k[i];
+    for (int rep = 0; rep < 2; ++rep) {
+        if (gte_n<8>(kr, Consts::R)) {
+            (void)sub_n<8>(tmp, kr, Consts::R);
+            for (int i = 0; i < 8; ++i) kr[i] = tmp[i];
+        }
+    }
+    uint32_t flip = 0;
+    if (!gte_n<8>(SplitConsts::RHALF, kr)) {   // kr > (r-1)/2
+        (void)sub_n<8>(tmp, Consts::R, kr);
+        for (int i = 0; i < 8; ++i) kr[i] = tmp[i];
+        flip = 1;
+    }
+    // t = kr + floor(u0/2)   (< 2^255)
+    uint32_t t[8];
+    {
+        uint64_t c = 0;
+        for (int i = 0; i < 8; ++i) {
+            uint64_t v = (uint64_t)kr[i] + (i < 4 ? SplitConsts::LHALF[i] : 0u) + c;
+            t[i] = (uint32_t)v;
+            c = v >> 32;
+        }
+    }
+    // q = floor(t / u0): Barrett estimate floor(t*M / 2^384) (never too large, at most 2 too small), then correct
+    uint32_t tm[17];
+    mul_n<8, 9>(tm, t, SplitConsts::M);
+    uint32_t q[4] = {tm[12], tm[13], tm[14], tm[15]};
+    uint32_t ql[8];
+    mul_n<4, 4>(ql, q, Consts::U0);
+    uint32_t rem[8];
+    (void)sub_n<8>(rem, t, ql);   // < 3*u0 < 2^130
+    uint32_t lam5[5] = {Consts::U0[0], Consts::U0[1], Consts::U0[2], Consts::U0[3], 0u};
+    for (int rep = 0; rep < 2; ++rep) {
+        if (gte_n<5>(rem, lam5)) {
+            uint32_t r5[5];
+            (void)sub_n<5>(r5, rem, lam5);
+            for (int i = 0; i < 5; ++i) rem[i] = r5[i];
+            uint64_t c = 1;
+            for (int i = 0; i < 4; ++i) {
+                uint64_t v = (uint64_t)q[i] + c;
+                q[i] = (uint32_t)v;
+                c = v >> 32;
+            }
+        }
+    }
+    for (int i = 0; i < 4; ++i) k2abs[i] = q[i];
+    // k1 = rem - floor(u0/2), |k1| <= u0/2
+    uint32_t neg1 = 0;
+    if (gte_n<4>(rem, SplitConsts::LHALF)) {
+        (void)sub_n<4>(k1abs, rem, SplitConsts::LHALF);
+    } else {
+        (void)sub_n<4>(k1abs, SplitConsts::LHALF, rem);
+        neg1 = 1;
+    }
+    return (flip ^ neg1) | ((flip ^ 1u) << 1);
+}
+
 }  // namespace glv
 }  // namespace msm

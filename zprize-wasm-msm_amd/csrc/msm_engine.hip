@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -37,7 +38,7 @@ namespace msm {
 
 // launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
 template <class F>
-void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
                        uint32_t tail_block);
 template <class F>
@@ -178,6 +179,59 @@ __global__ void __launch_bounds__(256) k_digits_c16(const uint8_t* __restrict__ 
         }
     }
 }
+
+// GLV path (BLS12-381 G1, c = 16, whole 32-byte scalars; SURVEY.md 8f rank 1, constants of build_glv.js:15-22): every
+// scalar is split into two signed 127-bit halves (glv::split_centered).  Virtual item 2i is (P_i, k1), item 2i+1 is
+// (phi(P_i), k2) with phi(x, y) = (beta*x, y): 2n items, 8 windows and no carry out of the last one -- the same number of
+// bucket additions as 16 windows over n items, but half the buckets to initialise, reduce and Horner-combine.
+__global__ void __launch_bounds__(256) k_digits_glv(const uint8_t* __restrict__ scalars, uint32_t n, Geom g, uint16_t* __restrict__ dig) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + (size_t)i * 2;
+    uint4 lo = sp[0], hi = sp[1];
+    uint32_t k[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t h[2][4];
+    uint32_t sg = glv::split_centered(k, h[0], h[1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        uint32_t carry = 0;
+        const bool sneg = ((sg >> j) & 1u) != 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 8; ++w) {
+            uint32_t raw = (h[j][w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
+            raw += carry;
+            // raw == 2^15 may be written +2^15 or -2^15 (+carry): take the form whose final sign is positive, because the
+            // code "negative, magnitude 2^15" (0xFFFF) is the zero-digit marker.  The halves are below 2^127 (top digit
+            // <= 0x5623), so this never carries out of the last window.
+            bool negd = raw > 0x8000u || (raw == 0x8000u && sneg);
+            uint32_t mag = negd ? 0x10000u - raw : raw;
+            carry = negd ? 1u : 0u;
+            if ((w % g.nshards) == g.shard) {
+                uint32_t code = mag == 0 ? DIGIT_ZERO : (((negd != sneg) ? 0x8000u : 0u) | (mag - 1));
+                dig[(size_t)(w / g.nshards) * g.n + 2 * i + j] = (uint16_t)code;
+            }
+        }
+    }
+}
+// x-coordinates of the endomorphism images: xbeta[i] = beta * x_i (y is shared with the original point)
+template <class F>
+__global__ void __launch_bounds__(256) k_glv_xbeta(const uint8_t* __restrict__ affine, uint32_t n, uint8_t* __restrict__ xbeta) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F x = load16<F>(affine + (size_t)i * sizeof(Affine<F>));
+    F beta;
+#pragma unroll
+    for (int j = 0; j < F::N; ++j) beta.v[j] = glv::Consts::BETA[j];
+    store16(xbeta + (size_t)i * sizeof(F), F::canon(F::mul(x, beta)));
+}
+template <class F>
+struct GlvField {
+    static constexpr bool value = false;
+};
+template <>
+struct GlvField<Fp<Bls12381Fp>> {
+    static constexpr bool value = true;
+};
 
 __global__ void __launch_bounds__(SORT_BLOCK) k_coarse_hist(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
                                                               uint32_t ntile, uint32_t* __restrict__ M) {
@@ -694,6 +748,7 @@ using namespace msm;
 // the sort + accumulation of the next call (throughput-bound, stream A).
 struct Slot {
     DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
+    DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
@@ -709,7 +764,7 @@ struct Slot {
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
-    DevBuf* bufs[20] = {&d_dig, &d_tmp, &d_M, &d_Mscan, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+    DevBuf* bufs[21] = {&d_xbeta, &d_dig, &d_tmp, &d_M, &d_Mscan, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_cursor, &d_order, &d_bins, &d_tiles, &d_sorted, &d_buckets, &d_partials};
 };
 
@@ -726,6 +781,7 @@ struct msm_amd_ctx {
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
     float timings[8] = {};
@@ -873,6 +929,21 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.half = 1u << (g.c - 1);
     g.shard = a.shard;
     g.nshards = a.nshards;
+    // GLV path: 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_digits_glv).  Same number of bucket
+    // additions, half the buckets.  It pays where the bucket reduction dominates (n <= 2^17: 8-15 % per call); from 2^18 up
+    // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
+    // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2
+    // forces the path (tests, experiments).
+    bool use_glv = false;
+    if constexpr (GlvField<F>::value)
+        use_glv = ctx->glv_mode != 0 && !ctx->sort_atomic && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+                  (a.n <= (1u << 17) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
+    const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
+    if (use_glv) {
+        g.n = nv;
+        g.nbits = 128;
+        g.W = 8;
+    }
     g.Wl = 0;
     for (uint32_t w = 0; w < g.W; ++w)
         if (w % g.nshards == g.shard) ++g.Wl;
@@ -897,6 +968,14 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_affine.p);
         d_bases = (const uint8_t*)sl->d_affine.p;
     }
+    const uint8_t* d_xbeta = nullptr;
+    if constexpr (GlvField<F>::value) {
+        if (use_glv) {
+            if (int rc = ensure(ctx, sl->d_xbeta, (size_t)a.n * sizeof(F))) return rc;
+            k_glv_xbeta<F><<<(a.n + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_xbeta.p);
+            d_xbeta = (const uint8_t*)sl->d_xbeta.p;
+        }
+    }
     HIPCHK(ctx, hipEventRecord(sl->ev[1], st));
 
     const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
@@ -906,7 +985,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * a.n * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nv * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
     uint32_t* count = (uint32_t*)sl->d_count.p;
     uint32_t* offset = (uint32_t*)sl->d_offset.p;
@@ -951,11 +1030,11 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // ---- 1. digit codes + coarse histogram
         const uint32_t fine_bits = std::min(8u, g.c - 1);
         const uint32_t cb = g.half >> fine_bits;                      // coarse bins per window (<= 128)
-        const uint32_t stile = (a.n + SORT_TILE - 1) / SORT_TILE;
+        const uint32_t stile = (nv + SORT_TILE - 1) / SORT_TILE;
         const size_t NM = (size_t)g.Wl * cb * stile;                   // count matrix entries (+1 for the total)
         const uint32_t mtiles = (uint32_t)((NM + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        if (int rc = ensure(ctx, sl->d_dig, (size_t)g.Wl * a.n * 2)) return rc;
-        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * a.n * 8)) return rc;
+        if (int rc = ensure(ctx, sl->d_dig, (size_t)g.Wl * nv * 2)) return rc;
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * 8)) return rc;
         if (int rc = ensure(ctx, sl->d_M, (NM + 1) * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_Mscan, (NM + 1) * 4 * 2)) return rc;
         if (int rc = ensure(ctx, sl->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
@@ -966,11 +1045,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         uint32_t* Mscan = (uint32_t*)sl->d_Mscan.p;
         uint32_t* Mdummy = Mscan + (NM + 1);
         const bool c16 = g.c == 16 && a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && g.W == 17 && (((uintptr_t)d_scalars & 15) == 0);
-        if (c16) k_digits_c16<<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        if (use_glv) k_digits_glv<<<nblk, 256, 0, st>>>(d_scalars, a.n, g, dig);
+        else if (c16) k_digits_c16<<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         else if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
         HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
-        k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, M);
+        k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, M);
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. scan of the count matrix
         k_scan_tile_sums<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles);
@@ -978,7 +1058,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_scan_apply<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles, Mscan, Mdummy);
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
-        k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, a.n, fine_bits, cb, stile, Mscan, tmp);
+        k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, Mscan, tmp);
         k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
@@ -989,11 +1069,14 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     st = ctx->stream;
     HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
     HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
-    // segment length: 2x the mean bucket population, at least 32 (a Poisson bucket practically never exceeds it);
-    // longer buckets -- adversarial scalars, or the few buckets of a narrow top window when the scalar width is
-    // not a multiple of c -- are cut into segments, which bounds the longest dependent chain of additions
-    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, 2u * ((a.n + g.half - 1) / g.half));
-    const size_t max_segs = (size_t)g.Wl * a.n / seg + 1;
+    // segment length: mean bucket population + 8 standard deviations of a Poisson bucket, at least 32: random inputs
+    // practically never exceed it (a handful of segments queued for the tail kernels costs a serial chain of `seg` additions
+    // on one lane, ~0.6 ms at seg = 32, which a 2x-the-mean rule paid at mean = 16).  Longer buckets -- adversarial scalars, or
+    // the few buckets of a narrow top window when the scalar width is not a multiple of c -- are cut into segments, which
+    // bounds the longest dependent chain of additions.
+    const uint32_t mean = (nv + g.half - 1) / g.half;
+    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, mean + 8u * (uint32_t)std::ceil(std::sqrt((double)mean)) + 8u);
+    const size_t max_segs = (size_t)g.Wl * nv / seg + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
@@ -1002,12 +1085,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
     uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
-    launch_accumulate<FK>(st, d_bases, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+    launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                           (uint8_t*)sl->d_segout.p, tail_block);
     HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
     if (split < NB) {
         HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
-        launch_accumulate<FK>(st, d_bases, sorted, offset, count, order + split, NB - split, buckets, seg, sl->d_tailctl.p, sl->d_work.p,
+        launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order + split, NB - split, buckets, seg, sl->d_tailctl.p, sl->d_work.p,
                               sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
     }
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
@@ -1416,6 +1499,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
     if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
+    if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "slots")) {
         if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 4]"; return MSM_AMD_EINVAL; }
         for (Slot& sl : ctx->slots)
@@ -1570,6 +1654,15 @@ int msm_amd_glv_decompose_scalar(const uint8_t* scalar32, uint8_t* out64, uint32
     memset(out64, 0, 64);
     memcpy(out64, k1, 16);
     memcpy(out64 + 32, k2, 16);
+    return 0;
+}
+int msm_amd_glv_split(const uint8_t* scalar32, uint8_t* out32, uint32_t* sign) {
+    if (!scalar32 || !out32 || !sign) return MSM_AMD_EINVAL;
+    uint32_t k[8], k1[4], k2[4];
+    memcpy(k, scalar32, 32);
+    *sign = glv::split_centered(k, k1, k2);
+    memcpy(out32, k1, 16);
+    memcpy(out32 + 16, k2, 16);
     return 0;
 }
 int msm_amd_glv_endomorphism(const uint8_t* point_affine, uint32_t sign, uint8_t* out_affine) {

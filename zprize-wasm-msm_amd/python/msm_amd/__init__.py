@@ -70,6 +70,7 @@ def load_library(path=None):
         getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_curve_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
+    L.msm_amd_glv_split.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
     L.msm_amd_glv_preprocess.argtypes = [vp, u32, vp, vp, u32, vp, vp]
     L.msm_amd_dev_alloc.argtypes = [vp, c.c_size_t, c.POINTER(vp)]
@@ -366,6 +367,16 @@ def glv_decompose_scalar(scalar32):
     if L.msm_amd_glv_decompose_scalar(bytes(scalar32), out, ctypes.byref(sign)):
         raise MsmAmdError("msm_amd_glv_decompose_scalar failed")
     return int.from_bytes(out.raw[:32], "little"), int.from_bytes(out.raw[32:], "little"), sign.value
+
+
+def glv_split(scalar32):
+    """The engine's own centred split (msm_amd_glv_split): returns (|k1|, |k2|, sign word)."""
+    L = load_library()
+    out = ctypes.create_string_buffer(32)
+    sign = ctypes.c_uint32()
+    if L.msm_amd_glv_split(bytes(scalar32), out, ctypes.byref(sign)):
+        raise MsmAmdError("msm_amd_glv_split failed")
+    return int.from_bytes(out.raw[:16], "little"), int.from_bytes(out.raw[16:], "little"), sign.value
 
 
 def glv_endomorphism(point_affine, sign):
