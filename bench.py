@@ -213,11 +213,13 @@ def main():
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms},
-            # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  2750 v_mad_u64_u32 per
-            # bucket addition (8 multiplies x 288 + 2 squarings x 222) against the measured full-rate peak of 36.3 T mad/s
-            # (profiles/r01_valu_rates_microbench.txt); every mad is paired with a v_addc_co_u32, so ~50 % is the ceiling.
-            "roofline_valu": ({"kernel": "k_accumulate", "achieved": geom["entries"] * 2750 / (acc_ms * 1e-3) / 1e12, "peak": 36.3, "unit": "T mad/s",
-                               "frac": geom["entries"] * 2750 / (acc_ms * 1e-3) / 1e12 / 36.3} if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
+            # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  3542 v_mad_u64_u32 per bucket
+            # addition (6 products x 392 + one fused two-product reduction 588 + 2 squarings x 301, field_u.hpp) against the
+            # measured full-rate peak of 36.3 T mad/s at 2.4 GHz (profiles/r01_valu_rates_microbench.txt); the mads are ~75 % of
+            # the kernel's VALU instructions (profiles/pmc_accumulate.json: SQ_INSTS_VALU) and the chip clocks this kernel
+            # at ~1.95 GHz (GRBM_GUI_ACTIVE), so ~0.6 is the practical ceiling of this fraction.
+            "roofline_valu": ({"kernel": "k_accumulate", "achieved": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12, "peak": 36.3, "unit": "T mad/s",
+                               "frac": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12 / 36.3} if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
             "stages_ms": stages,
             "result_x_prefix": result[:8].hex(),
         }
