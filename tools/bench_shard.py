@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-rank cost of a window-sharded MSM, measured on ONE GPU: runs the shard `rank` of `world` alone, `depth` calls in
+flight, and prints ms per call.  (The 8-GPU scaling run is the driver's; this shows what one rank of it has to do.)"""
+import argparse
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "zprize-wasm-msm_amd", "python"))
+import numpy as np  # noqa: E402
+
+import msm_amd  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--logn", type=int, default=20)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--rank", type=int, default=0)
+    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--opt", action="append", default=[])
+    a = ap.parse_args()
+    n = 1 << a.logn
+    eng = msm_amd.Engine(0)
+    eng.set_option("slots", a.depth)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
+    C = eng.curve("bls12381")
+    pts = C.gen_points(1, 77, n)
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x3F
+    ds = eng.alloc(n * 32).upload(sc.tobytes())
+    for _ in range(3):
+        C.multiexp_shard(1, pts, ds, 32, n, a.rank, a.world)
+    t0 = time.perf_counter()
+    fl = []
+    for _ in range(a.steps):
+        fl.append(C.multiexp_shard_async(1, pts, ds, 32, n, a.rank, a.world))
+        if len(fl) == a.depth:
+            fl.pop(0).wait()
+    while fl:
+        fl.pop(0).wait()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(f"n=2^{a.logn} shard {a.rank}/{a.world} depth {a.depth}: {dt * 1e3:.3f} ms per call; timings of last call {eng.timings()}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1065,8 +1065,11 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
-    // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation)
-    st = ctx->stream;
+    // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation).
+    // A SMALL accumulation (fewer than two waves per SIMD: few owned windows of a sharded call, small n) cannot fill the
+    // chip by itself, so it goes to the slot's own stream instead and may overlap the accumulations of the other calls in flight.
+    const bool small_acc = NB < 2u * 1024u * 64u && !split_mode;
+    st = small_acc ? sl->stream_c : ctx->stream;
     HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
     HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
     // segment length: mean bucket population + 8 standard deviations of a Poisson bucket, at least 32: random inputs
@@ -1108,7 +1111,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     auto plan = [&](uint32_t nbuckets) {
         Plan p;
         p.L = ctx->force_L ? ctx->force_L
-                           : others_pending ? std::min(32u, std::max(1u, g.half / 1024u))
+                           : others_pending ? std::min(32u, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
                                             : std::min(8u, std::max(1u, (nbuckets + 65535u) / 65536u));
         p.lanes = (g.half + p.L - 1) / p.L;
         p.rblock = std::min(256u, std::max(64u, p.lanes));
@@ -1265,6 +1268,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream_s);
         (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(sl->stream_c);
         (void)hipStreamSynchronize(sl->stream_b);
         return rc;
     }
