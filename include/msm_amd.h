@@ -145,6 +145,11 @@ int msm_amd_batch_u_to_lem(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
  * in the reference).  out_flags is a host buffer of n bytes unless MSM_AMD_DEVICE_PTRS is set.                           */
 int msm_amd_batch_in_curve_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *points, uint32_t n,
                                   uint8_t *out_flags);
+/* g1m_inGroupAffine / g2m_inGroupAffine (bls12381/build_bls12381.js:1494-1576, 1370-1480), batched on the GPU:
+ * out_flags[i] = 1 for affine infinity, 0 for a point off the curve, else 1 iff the point lies in the order-r subgroup.
+ * BLS12-381 only, as in the reference.                                                                          */
+int msm_amd_batch_in_group_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *points, uint32_t n,
+                                  uint8_t *out_flags);
 
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),

@@ -669,6 +669,29 @@ EXPORT int oracle_g_batch_in_curve_affine(int curve, int group, const u8 *in, u3
     }
     return 0;
 }
+/* bls12381/build_bls12381.js:1494-1576 (g1m_inGroupAffine) and :1370-1480 (g2m_inGroupAffine): 1 for affine infinity, 0 off the
+ * curve, else membership in the order-r subgroup.  The reference decides membership with endomorphism identities (Scott 2021);
+ * this restatement uses the definition, r*P == infinity, which is the same predicate on curve points.  BLS12-381 only (the
+ * reference builds no such export for BN254). */
+EXPORT int oracle_g_batch_in_group_affine(int curve, int group, const u8 *in, u32 n, u8 *flags) {
+    static const u8 R_BLS[32] = {0x01, 0x00, 0x00, 0x00, 0xff, 0xff, 0xff, 0xff, 0xfe, 0x5b, 0xfe, 0xff, 0x02, 0xa4, 0xbd, 0x53,
+                                 0x05, 0xd8, 0xa1, 0x09, 0x08, 0xd8, 0x39, 0x33, 0x48, 0x7d, 0x9d, 0x29, 0x53, 0xa7, 0xed, 0x73};
+    if (curve != 0) return -1;
+    Fld K; if (mk(&K, curve, group)) return -1;
+    u64 b[MAXE]; curve_b(&K, curve, b);
+    for (u32 i = 0; i < n; i++) {
+        u64 a[2 * MAXE], y2[MAXE], x3[MAXE], j[3 * MAXE], rp[3 * MAXE];
+        memcpy(a, in + (size_t)i * 2 * K.nw * 8, 2 * K.nw * 8);
+        if (g_is_zero_affine(&K, a)) { flags[i] = 1; continue; }
+        f_square(&K, a + K.nw, y2);
+        f_square(&K, a, x3); f_mul(&K, a, x3, x3); f_add(&K, x3, b, x3);
+        if (!f_eq(&K, y2, x3)) { flags[i] = 0; continue; }
+        g_to_jacobian(&K, a, j);
+        g_times_scalar(&K, j, R_BLS, 32, rp);
+        flags[i] = (u8)g_is_zero(&K, rp);
+    }
+    return 0;
+}
 static void reverse_bytes(const u8 *in, size_t n, u8 *out) { for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i]; }
 /* build_curve_jacobian_a0.js:1206-1231,1413 (LEMtoU / batchLEMtoU): affine little-endian Montgomery ->
  * x || y big-endian plain; infinity -> zeros with first byte 0x40 */

@@ -131,6 +131,12 @@ class Oracle:
         assert self.L.oracle_g_batch_in_curve_affine(self.cid, self.group, bytes(aff), n, out) == 0
         return list(out.raw[:n])
 
+    def batch_in_group_affine(self, aff):
+        n = len(aff) // self.asz
+        out = _buf(max(1, n))
+        assert self.L.oracle_g_batch_in_group_affine(self.cid, self.group, bytes(aff), n, out) == 0
+        return list(out.raw[:n])
+
     # --- field ops ---
     def f_mul(self, x, y): return self._g2("oracle_f_mul", x, y, self.fsz)
     def f_add(self, x, y): return self._g2("oracle_f_add", x, y, self.fsz)

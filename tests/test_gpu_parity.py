@@ -272,6 +272,23 @@ def test_split_window_groups(eng, orc):
         eng.set_option("split", 0)
 
 
+def test_in_group_affine_matches_reference(eng, orc):
+    """Batched subgroup check on the GPU == the reference's g?m_inGroupAffine flags (golden_ingroup.json) and the oracle's."""
+    import json
+    import os
+    with open(os.path.join(gu.GOLDEN, "golden_ingroup.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        C = eng.curve(c["curve"])
+        O = orc.Oracle(c["curve"], c["group"])
+        aff = bytes.fromhex(c["affine_in"])
+        assert C.batch_in_group_affine(c["group"], aff) == c["inGroupAffine"]
+        big = aff * 7 + gu.pool_points(c["curve"], c["group"], list(range(40)))
+        assert C.batch_in_group_affine(c["group"], big) == O.batch_in_group_affine(big)
+    with pytest.raises(Exception):
+        eng.curve("bn128").batch_in_group_affine(1, bytes(64))
+
+
 def test_glv_path_matches_oracle_and_plain_path(eng, orc):
     """BLS12-381 G1 with whole 32-byte scalars and c = 16 runs through the engine's GLV split (2n virtual points, 8 windows):
     same bytes as the oracle and as the plain 16-window path, including scalars >= r, around r/2, 0, 1 and an affine infinity."""

@@ -38,14 +38,22 @@ def main():
         C.multiexp_shard(1, pts, ds, 32, n, a.rank, a.world)
     t0 = time.perf_counter()
     fl = []
+    t_submit = t_wait = 0.0
     for _ in range(a.steps):
+        t1 = time.perf_counter()
         fl.append(C.multiexp_shard_async(1, pts, ds, 32, n, a.rank, a.world))
+        t2 = time.perf_counter()
+        t_submit += t2 - t1
         if len(fl) == a.depth:
             fl.pop(0).wait()
+            t_wait += time.perf_counter() - t2
     while fl:
+        t2 = time.perf_counter()
         fl.pop(0).wait()
+        t_wait += time.perf_counter() - t2
     dt = (time.perf_counter() - t0) / a.steps
-    print(f"n=2^{a.logn} shard {a.rank}/{a.world} depth {a.depth}: {dt * 1e3:.3f} ms per call; timings of last call {eng.timings()}")
+    print(f"n=2^{a.logn} shard {a.rank}/{a.world} depth {a.depth}: {dt * 1e3:.3f} ms per call (host: submit {t_submit / a.steps * 1e3:.3f} ms, wait {t_wait / a.steps * 1e3:.3f} ms); "
+          f"timings of last call {eng.timings()}")
 
 
 if __name__ == "__main__":

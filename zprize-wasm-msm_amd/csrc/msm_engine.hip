@@ -673,6 +673,33 @@ __global__ void __launch_bounds__(256) k_batch_in_curve_affine(const uint8_t* __
     flags[i] = F::sub(y2, x3b).is_zero() ? 1 : 0;
 }
 
+// bls12381/build_bls12381.js:1494-1576 / :1370-1480 (g?m_inGroupAffine), batched: 1 for affine infinity, 0 off the curve, else
+// r*P == infinity (the definition; the reference reaches the same predicate through endomorphism identities).  One lane per
+// point, 255 doublings + ~128 mixed additions; a validation pass that runs once per base table.
+template <class F>
+__global__ void __launch_bounds__(256) k_batch_in_group_affine(const uint8_t* __restrict__ aff, uint32_t n, F b, uint8_t* __restrict__ flags) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load16<Affine<F>>(aff + (size_t)i * sizeof(Affine<F>));
+    if (p.is_inf()) {
+        flags[i] = 1;
+        return;
+    }
+    F y2 = F::sqr(p.y);
+    F x3b = F::add(F::mul(p.x, F::sqr(p.x)), b);
+    if (!F::sub(y2, x3b).is_zero()) {
+        flags[i] = 0;
+        return;
+    }
+    using P = typename F::Params;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int bit = 254; bit >= 0; --bit) {
+        acc = XYZZ<F>::dbl_ni(acc);
+        if ((P::RORDER[bit >> 5] >> (bit & 31)) & 1u) XYZZ<F>::madd(acc, p.x, p.y);
+    }
+    flags[i] = acc.is_inf() ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // GLV pre-pass (BLS12-381 G1): build_glv.js:178-267 (_preprocessEndomorphism), one lane per pair.
 //   points_out[2i]   = (x, k1 >= 0 ? y : -y)        scalars_out[2i]   = |k1|  (32 bytes, upper 16 zero)
@@ -1395,7 +1422,7 @@ static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flag
 
 
 template <class F>
-static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* points, uint32_t n, uint8_t* out) {
+static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* points, uint32_t n, uint8_t* out, bool group_check = false) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
@@ -1415,7 +1442,8 @@ static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* 
         }
         (void)hipMemcpyAsync(di, points, in_b, hipMemcpyHostToDevice, st);
     }
-    k_batch_in_curve_affine<F><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, b, (uint8_t*)dout);
+    if (group_check) k_batch_in_group_affine<F><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, b, (uint8_t*)dout);
+    else k_batch_in_curve_affine<F><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, b, (uint8_t*)dout);
     hipError_t e = hipGetLastError();
     if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, n, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1628,6 +1656,21 @@ int msm_amd_batch_u_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
     return conv(ctx, 3, curve, group, flags, u_in, n, aff_out);
 }
 
+int msm_amd_batch_in_group_affine(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* points, uint32_t n, uint8_t* out_flags) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n && (!points || !out_flags)) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    if (curve != MSM_AMD_BLS12381 || (group != 1 && group != 2)) {
+        ctx->err = "inGroupAffine exists for BLS12-381 only (as in the reference)";
+        return MSM_AMD_EINVAL;
+    }
+    if (n == 0) return 0;
+    using P = Bls12381Fp;
+    if (group == 1) return in_curve_t<Fp<P>>(ctx, fp_from<P>(P::B1), flags, points, n, out_flags, true);
+    return in_curve_t<Fp2<P>>(ctx, Fp2<P>{fp_from<P>(P::B2_0), fp_from<P>(P::B2_1)}, flags, points, n, out_flags, true);
+}
 int msm_amd_batch_in_curve_affine(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* points, uint32_t n, uint8_t* out_flags) {
     if (!ctx) return MSM_AMD_EINVAL;
     if (n == 0) return 0;

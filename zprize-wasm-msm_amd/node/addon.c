@@ -39,6 +39,7 @@ static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_dev_alloc)(msm_amd_ctx *, size_t, void **);
 static int (*p_dev_free)(msm_amd_ctx *, void *);
 static int (*p_h2d)(msm_amd_ctx *, void *, const void *, size_t);
+static int (*p_check[2])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint8_t *);
 static int (*p_conv[4])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
@@ -77,6 +78,8 @@ static const char *load_engine(void) {
     SYM(p_dev_alloc, "msm_amd_dev_alloc")
     SYM(p_dev_free, "msm_amd_dev_free")
     SYM(p_h2d, "msm_amd_h2d")
+    SYM(p_check[0], "msm_amd_batch_in_curve_affine")
+    SYM(p_check[1], "msm_amd_batch_in_group_affine")
     SYM(p_conv[0], "msm_amd_batch_to_affine")
     SYM(p_conv[1], "msm_amd_batch_to_jacobian")
     SYM(p_conv[2], "msm_amd_batch_lem_to_u")
@@ -497,6 +500,38 @@ static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
     return res;
 }
 
+/* ---- point validation: batchCheck(ctx, which 0 = inCurveAffine | 1 = inGroupAffine, curve, group, Uint8Array affine points)
+ *      -> Uint8Array of 0/1 flags (g?m_inCurveAffine, build_curve_jacobian_a0.js:1330-1353; g?m_inGroupAffine, bls12381 only) ---- */
+static napi_value js_batch_check(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int which, curve, group;
+    const uint8_t *in;
+    size_t lin;
+    if (argc < 5 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &which) || get_i32(env, argv[2], &curve) ||
+        get_i32(env, argv[3], &group) || get_bytes(env, argv[4], &in, &lin) || which < 0 || which > 1 || (curve != 0 && curve != 1) ||
+        (group != 1 && group != 2)) {
+        napi_throw_type_error(env, NULL, "batchCheck(ctx, which 0..1, curve, group, Uint8Array)");
+        return NULL;
+    }
+    size_t asz = (size_t)2 * n8_of(curve) * group;
+    if (lin % asz) {
+        napi_throw_range_error(env, NULL, "input is not a whole number of affine points");
+        return NULL;
+    }
+    uint32_t n = (uint32_t)(lin / asz);
+    uint8_t *out = (uint8_t *)malloc((size_t)n + 1);
+    if (!out) return NULL;
+    int rc = p_check[which]((msm_amd_ctx *)ctx, curve, group, 0, in, n, out);
+    napi_value res = NULL;
+    if (rc) napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+    else res = bytes_out(env, out, (size_t)n);
+    free(out);
+    return res;
+}
+
 /* ---- GLV pre-pass (bls12381 G1): g1m_glv_decomposeScalar / _endomorphism / _preprocessEndomorphism ---- */
 static napi_value js_glv_decompose(napi_env env, napi_callback_info info) {
     size_t argc = 1;
@@ -597,6 +632,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"uploadBases", NULL, js_upload_bases, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpResident", NULL, js_multiexp_resident, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"batchCheck", NULL, js_batch_check, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvPreprocess", NULL, js_glv_preprocess, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -67,6 +67,13 @@ function instantiate(curveName, imports, opts) {
         ex[`${pf}_multiexpAffine_chunk`] = mk(0, true);
         // batch conversions either side of the MSM (same (pIn, n, pOut) signature as the reference's exports)
         const conv = (which, inSz, outSz) => (pIn, n, pOut) => u8().set(native.batchConvert(ctx, which, C.id, g, u8().subarray(pIn, pIn + n * inSz)), pOut);
+        // validation: the reference's single-point exports (return 0/1) and batched forms (n points -> Uint8Array of flags)
+        ex[`${pf}_inCurveAffine`] = (p) => native.batchCheck(ctx, 0, C.id, g, u8().subarray(p, p + 2 * fsz))[0];
+        ex[`${pf}_batchInCurveAffine`] = (pIn, n) => native.batchCheck(ctx, 0, C.id, g, u8().subarray(pIn, pIn + n * 2 * fsz));
+        if (curveName === "bls12381") {
+            ex[`${pf}_inGroupAffine`] = (p) => native.batchCheck(ctx, 1, C.id, g, u8().subarray(p, p + 2 * fsz))[0];
+            ex[`${pf}_batchInGroupAffine`] = (pIn, n) => native.batchCheck(ctx, 1, C.id, g, u8().subarray(pIn, pIn + n * 2 * fsz));
+        }
         ex[`${pf}_batchToAffine`] = conv(0, 3 * fsz, 2 * fsz);
         ex[`${pf}_batchToJacobian`] = conv(1, 2 * fsz, 3 * fsz);
         ex[`${pf}_batchLEMtoU`] = conv(2, 2 * fsz, 2 * fsz);
@@ -121,6 +128,8 @@ function curve(curveName, opts) {
             multiExp: run(FLAG_JACOBIAN, 3 * fsz),
             multiExpAffine: run(0, 2 * fsz),
             // buffer-in / buffer-out forms of the batch conversions (ffjavascript exposes them under these names)
+            inCurveAffine: async (buff) => native.batchCheck(ctx, 0, C.id, g, buff),
+            inGroupAffine: async (buff) => native.batchCheck(ctx, 1, C.id, g, buff),
             batchToAffine: async (buff) => native.batchConvert(ctx, 0, C.id, g, buff),
             batchToJacobian: async (buff) => native.batchConvert(ctx, 1, C.id, g, buff),
             batchLEMtoU: async (buff) => native.batchConvert(ctx, 2, C.id, g, buff),

@@ -112,6 +112,24 @@ async function main() {
             checked += 4;
         }
     }
+    // point validation (tests/golden/golden_ingroup.json): single-point exports and the batched forms
+    if (!hostOnly) {
+        const ing = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_ingroup.json")));
+        for (const c of ing.cases) {
+            const memory = new WebAssembly.Memory({ initial: 8 });
+            const m = msm.instantiate(c.curve, { memory });
+            const aff = Buffer.from(c.affine_in, "hex"), asz = aff.length / c.n, pA = 1024, pf = `g${c.group}m`;
+            new Uint8Array(memory.buffer).set(aff, pA);
+            const gr = Array.from(m[`${pf}_batchInGroupAffine`](pA, c.n)), cu = Array.from(m[`${pf}_batchInCurveAffine`](pA, c.n));
+            if (JSON.stringify(gr) !== JSON.stringify(c.inGroupAffine)) throw new Error("inGroupAffine flags differ");
+            if (JSON.stringify(cu) !== JSON.stringify(c.inCurveAffine)) throw new Error("inCurveAffine flags differ");
+            for (const i of [0, 6, 7, 8, c.n - 1]) {
+                if (m[`${pf}_inGroupAffine`](pA + i * asz) !== c.inGroupAffine[i]) throw new Error("inGroupAffine (single) differs");
+                if (m[`${pf}_inCurveAffine`](pA + i * asz) !== c.inCurveAffine[i]) throw new Error("inCurveAffine (single) differs");
+            }
+            checked += 2;
+        }
+    }
     // GLV: the reference's known answer (wasmcurves/test/glv.js:50-65) through the export-shaped surface
     {
         const kat = JSON.parse(fs.readFileSync(path.join(GOLD, "kats_glv.json")));

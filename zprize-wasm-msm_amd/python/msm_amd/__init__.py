@@ -69,6 +69,7 @@ def load_library(path=None):
     for _fn in ("msm_amd_batch_to_affine", "msm_amd_batch_to_jacobian", "msm_amd_batch_lem_to_u", "msm_amd_batch_u_to_lem"):
         getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_curve_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_batch_in_group_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_split.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
@@ -302,6 +303,14 @@ class Curve:
         n = len(points) // self.affine_bytes(group)
         out = ctypes.create_string_buffer(max(1, n))
         self.eng._chk(self.eng.L.msm_amd_batch_in_curve_affine(self.eng.ctx, self.cid, group, 0, points, n, out))
+        return list(out.raw[:n])
+
+    def batch_in_group_affine(self, group, points):
+        """g?m_inGroupAffine over a batch (bls12381 only): list of 0/1 flags"""
+        points = bytes(points)
+        n = len(points) // self.affine_bytes(group)
+        out = ctypes.create_string_buffer(max(1, n))
+        self.eng._chk(self.eng.L.msm_amd_batch_in_group_affine(self.eng.ctx, self.cid, group, 0, points, n, out))
         return list(out.raw[:n])
 
     # --- GLV pre-pass (bls12381 G1 only): g1m_glv_preprocessEndomorphism ----------------------------------
