@@ -2,5 +2,5 @@
 #include "bucket_kernels.hpp"
 namespace msm {
 using F_ = Fp<Bls12381Fp, true>;
-MSM_INSTANTIATE_BUCKET_KERNELS(F_)
+MSM_INSTANTIATE_TAIL_AND_REDUCE(F_)   // the accumulation kernel itself: bucket_g1_bls12381_acc.hip
 }  // namespace msm

@@ -2,5 +2,5 @@
 #include "bucket_kernels.hpp"
 namespace msm {
 using F_ = Fp<Bn254Fp, true>;
-MSM_INSTANTIATE_BUCKET_KERNELS(F_)
+MSM_INSTANTIATE_TAIL_AND_REDUCE(F_)   // the accumulation kernel itself: bucket_g1_bn254_acc.hip
 }  // namespace msm

@@ -1,0 +1,7 @@
+// Bucket ACCUMULATION kernel for BN254 G1: everything inline, one dependent chain of multiply-adds per field product.
+#define MSM_U_CHAINED_MADS 1
+#include "bucket_kernels.hpp"
+namespace msm {
+using F_ = Fp<Bn254Fp, true>;
+MSM_INSTANTIATE_ACCUMULATE(F_)
+}  // namespace msm

@@ -208,12 +208,18 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 }
 
 
+// The accumulation kernel proper and the rest (tail kernels, reduction) are instantiated in different translation units:
+// the former is compiled with MSM_U_CHAINED_MADS (field_u.hpp), the latter -- kernels that run few waves -- without.
 template <class F>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
-                       uint32_t tail_block) {
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
     k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
                                                        (uint4*)biglist);
+}
+template <class F>
+void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
+                            const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
+                            uint32_t tail_block) {
     k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
     k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
@@ -229,10 +235,14 @@ size_t bucket_bytes() {
     return sizeof(BU<F>);
 }
 
-#define MSM_INSTANTIATE_BUCKET_KERNELS(F)                                                                                                   \
-    template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*,   \
-                                       uint32_t, uint8_t*, uint32_t, void*, void*, void*, uint8_t*, uint32_t);                              \
+#define MSM_INSTANTIATE_ACCUMULATE(F)                                                                                                        \
+    template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
+                                       uint32_t, uint8_t*, uint32_t, void*, void*, void*);
+#define MSM_INSTANTIATE_TAIL_AND_REDUCE(F)                                                                                                   \
+    template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
+                                            uint32_t, void*, void*, void*, uint8_t*, uint32_t);                                              \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
     template size_t bucket_bytes<F>();
+#define MSM_INSTANTIATE_BUCKET_KERNELS(F) MSM_INSTANTIATE_ACCUMULATE(F) MSM_INSTANTIATE_TAIL_AND_REDUCE(F)
 
 }  // namespace msm

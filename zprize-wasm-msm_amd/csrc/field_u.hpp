@@ -179,6 +179,27 @@ MSM_HD auto fnorm(const Fu<P, LA, VA>& a) {
 // Montgomery product(s):  r = (a*b [+ c*d]) / R'  mod q,   r < (T/(R' q) + 1) q, limbs strictly normalised.
 // Product scanning: one 64-bit accumulator, one v_mad_u64_u32 per partial product.
 // ------------------------------------------------------------------------------------------
+// acc += a*b.  Plain C lets the compiler split a column into two interleaved chains (good for a kernel that runs one wave
+// per SIMD: the bucket reduction) at the price of one 64-bit add per column to join them.  A translation unit that defines
+// MSM_U_CHAINED_MADS (the G1 accumulation kernels: 3-4 waves per SIMD hide the dependent-issue latency) gets ONE chain per
+// multiplication instead -- the previous column's carry is simply the addend of the next column's first product: 482 instead
+// of 518 VALU instructions per 14-limb product.
+MSM_HD void umad(uint64_t& acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MSM_U_CHAINED_MADS)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+#else
+    acc += (uint64_t)a * b;
+#endif
+}
+// same with b a wave-uniform constant (modulus limb)
+MSM_HD void umad_c(uint64_t& acc, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MSM_U_CHAINED_MADS)
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "s"(b) : "vcc");
+#else
+    acc += (uint64_t)a * b;
+#endif
+}
+
 template <class P, bool TWO>
 MSM_HD void umont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* d) {
     using C = UC<P>;
@@ -190,24 +211,24 @@ MSM_HD void umont(uint32_t* __restrict__ r, const uint32_t* a, const uint32_t* b
     for (int k = 0; k < NL; ++k) {
 #pragma unroll
         for (int i = 0; i <= k; ++i) {
-            acc += (uint64_t)a[i] * b[k - i];
-            if constexpr (TWO) acc += (uint64_t)c[i] * d[k - i];
+            umad(acc, a[i], b[k - i]);
+            if constexpr (TWO) umad(acc, c[i], d[k - i]);
         }
 #pragma unroll
-        for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        for (int i = 0; i < k; ++i) umad_c(acc, m[i], P::UQ[k - i]);
         m[k] = ((uint32_t)acc * P::UNP) & C::MASK;
-        acc += (uint64_t)m[k] * P::UQ[0];
+        umad_c(acc, m[k], P::UQ[0]);
         acc >>= W;
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; ++k) {
 #pragma unroll
         for (int i = k - NL + 1; i < NL; ++i) {
-            acc += (uint64_t)a[i] * b[k - i];
-            if constexpr (TWO) acc += (uint64_t)c[i] * d[k - i];
+            umad(acc, a[i], b[k - i]);
+            if constexpr (TWO) umad(acc, c[i], d[k - i]);
         }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+        for (int i = k - NL + 1; i < NL; ++i) umad_c(acc, m[i], P::UQ[k - i]);
         r[k - NL] = (uint32_t)acc & C::MASK;
         acc >>= W;
     }
@@ -228,17 +249,17 @@ MSM_HD void umont_sqr(uint32_t* __restrict__ r, const uint32_t* a) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             int j = k - i;
-            if (j > i && j < NL) acc += (uint64_t)a[i] * d2[j];
+            if (j > i && j < NL) umad(acc, a[i], d2[j]);
         }
-        if ((k & 1) == 0) acc += (uint64_t)a[k / 2] * a[k / 2];
+        if ((k & 1) == 0) umad(acc, a[k / 2], a[k / 2]);
         if (k < NL) {
 #pragma unroll
-            for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+            for (int i = 0; i < k; ++i) umad_c(acc, m[i], P::UQ[k - i]);
             m[k] = ((uint32_t)acc * P::UNP) & C::MASK;
-            acc += (uint64_t)m[k] * P::UQ[0];
+            umad_c(acc, m[k], P::UQ[0]);
         } else {
 #pragma unroll
-            for (int i = k - NL + 1; i < NL; ++i) acc += (uint64_t)m[i] * P::UQ[k - i];
+            for (int i = k - NL + 1; i < NL; ++i) umad_c(acc, m[i], P::UQ[k - i]);
             r[k - NL] = (uint32_t)acc & C::MASK;
         }
         acc >>= W;

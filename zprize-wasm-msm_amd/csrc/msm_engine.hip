@@ -39,8 +39,11 @@ namespace msm {
 // launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
 template <class F>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
-                       uint32_t tail_block);
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+template <class F>
+void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
+                            const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
+                            uint32_t tail_block);
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials);
@@ -1115,13 +1118,16 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
     uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
-    launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
-                          (uint8_t*)sl->d_segout.p, tail_block);
+    launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+    launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                               (uint8_t*)sl->d_segout.p, tail_block);
     HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
     if (split < NB) {
         HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
         launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order + split, NB - split, buckets, seg, sl->d_tailctl.p, sl->d_work.p,
-                              sl->d_biglist.p, (uint8_t*)sl->d_segout.p, tail_block);
+                              sl->d_biglist.p);
+        launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                                   (uint8_t*)sl->d_segout.p, tail_block);
     }
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
     // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
