@@ -1,9 +1,11 @@
-// Bucket kernels for G2 of both curves (Fp2 coordinates; base-field multiplies out of line).
-#define MSM_U_OUTLINE_PRODUCTS 1   // base-field products out of line (field_u.hpp)
+// Tail and reduction kernels for G2 of both curves (Fp2 coordinates on lane pairs, curve_u.hpp UG2P).  These kernels run
+// few waves and chain full additions through out-of-line functions; the base-field products stay out of line too, which
+// keeps every device function far below the 128 KB that have hung this GPU.
+#define MSM_U_OUTLINE_PRODUCTS 1
 #include "bucket_kernels.hpp"
 namespace msm {
 using F2a_ = Fp2<Bls12381Fp>;
 using F2b_ = Fp2<Bn254Fp>;
-MSM_INSTANTIATE_BUCKET_KERNELS(F2a_)
-MSM_INSTANTIATE_BUCKET_KERNELS(F2b_)
+MSM_INSTANTIATE_TAIL_AND_REDUCE(F2a_)   // the accumulation kernels: bucket_g2_acc.hip
+MSM_INSTANTIATE_TAIL_AND_REDUCE(F2b_)
 }  // namespace msm

@@ -1,0 +1,9 @@
+// Bucket ACCUMULATION kernels for G2 of both curves: Fp2 coordinates distributed over lane pairs (field_u.hpp Fp2d), everything
+// inline.
+#include "bucket_kernels.hpp"
+namespace msm {
+using F2a_ = Fp2<Bls12381Fp>;
+using F2b_ = Fp2<Bn254Fp>;
+MSM_INSTANTIATE_ACCUMULATE(F2a_)
+MSM_INSTANTIATE_ACCUMULATE(F2b_)
+}  // namespace msm

@@ -44,6 +44,7 @@ MSM_D Affine<F> load_point(const uint8_t* __restrict__ bases, const uint8_t* __r
 }
 // (Requesting the point of entry k+1 before the addition of entry k was measured: no gain at 2 waves/SIMD, and at 3 waves
 // the 24 extra registers spill -- the gather latency is already covered by the other waves' ~4600 VALU instructions.)
+// For a lane-paired kind (UG2P) both lanes of a pair walk the same entries; each loads its own component of x and y.
 template <class F>
 MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted, uint32_t first,
                             uint32_t len) {
@@ -51,12 +52,25 @@ MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __
     BU<F> acc = BU<F>::inf();
     for (uint32_t k = 0; k < len; ++k) {
         const uint32_t e = sorted[first + k];
-        const Affine<F> p = load_point<F>(bases, xbeta, e & 0x7fffffffu);
-        const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
-        if (words_all_zero(w, 2 * K::WORDS)) continue;   // affine infinity (build_curve_jacobian_a0.js:124-171)
-        auto x2 = K::load(w);
-        auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
-        BU<F>::madd(acc, x2, y2);
+        if constexpr (K::LANES == 1) {
+            const Affine<F> p = load_point<F>(bases, xbeta, e & 0x7fffffffu);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
+            if (words_all_zero(w, 2 * K::WORDS)) continue;   // affine infinity (build_curve_jacobian_a0.js:124-171)
+            auto x2 = K::load(w);
+            auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
+            BU<F>::madd(acc, x2, y2);
+        } else {
+            using B = typename F::B;                          // base field of the packed Fp2 coordinate: x = c0 || c1, y = c0 || c1
+            const uint8_t* pp = bases + (size_t)(e & 0x7fffffffu) * sizeof(Affine<F>) + pair_parity() * sizeof(B);
+            const B xo = load16<B>(pp);
+            const B yo = load16<B>(pp + sizeof(F));
+            const uint32_t z = (words_all_zero(xo.v, B::N) && words_all_zero(yo.v, B::N)) ? 1u : 0u;
+            if (z & pair_xchg(z)) continue;                   // all four components zero
+            typename K::In x2{u_from_packed<typename K::Params>(xo.v)};
+            typename K::In yl{u_from_packed<typename K::Params>(yo.v)};
+            auto y2 = fcneg(yl, (e >> 31) != 0);
+            BU<F>::madd(acc, x2, y2);
+        }
     }
     return acc;
 }
@@ -79,21 +93,23 @@ struct InlineAdds<Fp<P, true>> {
 #endif
 template <class F>
 struct AccWaves {
-    static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : 1;
+    static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : (UKind<F>::type::LANES == 2 ? 2 : 1);
 };
 template <class F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
                                                      TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
-    uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t T = UKind<F>::type::LANES;   // lanes per bucket (2: Fp2 components on a lane pair)
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = gt / T, sub = gt % T;
     if (r >= nb) return;
     uint32_t b = order[r];
     uint32_t cnt = count[b];
     uint32_t off = offset[b];
     BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, seg));
-    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
-    if (cnt > seg) {
+    store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
+    if (cnt > seg && sub == 0) {
         uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
         uint32_t base = atomicAdd(&ctl->nwork, extra);
         uint32_t bi = atomicAdd(&ctl->nbig, 1u);
@@ -107,12 +123,14 @@ __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restri
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                           const TailCtl* __restrict__ ctl, const uint2* __restrict__ work, uint32_t seg,
                                                           uint8_t* __restrict__ seg_out) {
+    constexpr uint32_t T = UKind<F>::type::LANES;
     const uint32_t nwork = ctl->nwork;
-    for (uint32_t item = blockIdx.x * blockDim.x + threadIdx.x; item < nwork; item += gridDim.x * blockDim.x) {
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t item = gt / T; item < nwork; item += gridDim.x * blockDim.x / T) {
         uint2 w = work[item];
         uint32_t len = min(seg, count[w.x] - w.y);
         BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[w.x] + w.y, len);
-        store16(seg_out + (size_t)item * sizeof(BU<F>), acc);
+        store16(seg_out + ((size_t)item * T + gt % T) * sizeof(BU<F>), acc);
     }
 }
 
@@ -121,25 +139,27 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
                                                        const uint8_t* __restrict__ seg_out, uint8_t* __restrict__ buckets) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, nlt = blockDim.x / T;   // logical lane, component, logical lanes
     const uint32_t nbig = ctl->nbig;
     for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         uint4 d = biglist[bi];   // bucket, first segment, number of segments
         BU<F> loc = BU<F>::inf();
-        for (uint32_t j = threadIdx.x; j < d.z; j += blockDim.x)
-            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + (size_t)(d.y + j) * sizeof(BU<F>)));
+        for (uint32_t j = lt; j < d.z; j += nlt)
+            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
         sh[threadIdx.x] = loc;
         __syncthreads();
-        for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) {
+        for (uint32_t s = nlt / 2; s > 0; s >>= 1) {
+            if (lt < s) {
                 BU<F> a = sh[threadIdx.x];
-                BU<F> bb = sh[threadIdx.x + s];
+                BU<F> bb = sh[threadIdx.x + s * T];
                 sh[threadIdx.x] = BU<F>::add_ni(a, bb);
             }
             __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            BU<F> cur = load16<BU<F>>(buckets + (size_t)d.x * sizeof(BU<F>));
-            store16(buckets + (size_t)d.x * sizeof(BU<F>), BU<F>::add_ni(cur, sh[0]));
+        if (lt == 0) {
+            BU<F> cur = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
+            store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), BU<F>::add_ni(cur, sh[threadIdx.x]));
         }
         __syncthreads();
     }
@@ -167,9 +187,11 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
                                                         uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, nlt = blockDim.x / T;
     uint32_t w = blockIdx.x / wgs_per_window;
     uint32_t wg = blockIdx.x % wgs_per_window;
-    uint32_t t = wg * blockDim.x + threadIdx.x;
+    uint32_t t = wg * nlt + lt;
     BU<F> res = BU<F>::inf();
     if (t < lanes_per_window) {
         uint32_t base = t * L;
@@ -177,7 +199,7 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
         BU<F> sum = BU<F>::inf();
         for (int j = (int)L - 1; j >= 0; --j) {
             if (base + j < half) {
-                BU<F> bk = load16<BU<F>>(buckets + ((size_t)w * half + base + j) * sizeof(BU<F>));
+                BU<F> bk = load16<BU<F>>(buckets + (((size_t)w * half + base + j) * T + sub) * sizeof(BU<F>));
                 run = radd<F>(run, bk);
             }
             sum = radd<F>(sum, run);
@@ -195,16 +217,16 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
     }
     sh[threadIdx.x] = res;
     __syncthreads();
-    for (int d = blockDim.x / 2; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) {
+    for (uint32_t d = nlt / 2; d > 0; d >>= 1) {
+        if (lt < d) {
             BU<F> a = sh[threadIdx.x];
-            BU<F> bb = sh[threadIdx.x + d];
+            BU<F> bb = sh[threadIdx.x + d * T];
             sh[threadIdx.x] = radd<F>(a, bb);
         }
         __syncthreads();
     }
-    // leaves the GPU: back to the canonical packed image XYZZ<F> that the host combine reads
-    if (threadIdx.x == 0) sh[0].to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
+    // leaves the GPU: back to the canonical packed image XYZZ<F> that the host combine reads (a lane pair writes one component each)
+    if (lt == 0) sh[threadIdx.x].to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
 }
 
 
@@ -213,26 +235,29 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 template <class F>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
-    k_accumulate<F><<<(nb + 255) / 256, 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl, (uint2*)work,
-                                                       (uint4*)biglist);
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    k_accumulate<F><<<(uint32_t)(((uint64_t)nb * T + 255) / 256), 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
+                                                                                (uint2*)work, (uint4*)biglist);
 }
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
                             uint32_t tail_block) {
     k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
-    k_combine_tail<F><<<64, tail_block, (size_t)tail_block * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
+    constexpr uint32_t T = UKind<F>::type::LANES;   // tail_block and rblock count LOGICAL lanes (points); a point takes T threads
+    k_combine_tail<F><<<64, tail_block * T, (size_t)tail_block * T * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials) {
-    k_bucket_reduce<F><<<nparts, rblock, (size_t)rblock * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials);
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    k_bucket_reduce<F><<<nparts, rblock * T, (size_t)rblock * T * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials);
 }
 
 // bytes of one bucket in HBM (the engine sizes its bucket arrays and LDS tiles with this)
 template <class F>
 size_t bucket_bytes() {
-    return sizeof(BU<F>);
+    return sizeof(BU<F>) * UKind<F>::type::LANES;
 }
 
 #define MSM_INSTANTIATE_ACCUMULATE(F)                                                                                                        \

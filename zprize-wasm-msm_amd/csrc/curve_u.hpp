@@ -48,6 +48,14 @@ template <class A, class B, class C_, class D>
 MSM_HD auto fmulsub(const Fp2u<A>& a, const Fp2u<B>& b, const Fp2u<C_>& c, const Fp2u<D>& d) {
     return fnorm(fsub(fmul(a, b), fmul(c, d)));
 }
+template <class T, class A>
+MSM_HD T fstore(const Fp2d<A>& a) {
+    return {fstore<typename T::Base>(a.v)};
+}
+template <class A, class B, class C_, class D>
+MSM_HD auto fmulsub(const Fp2d<A>& a, const Fp2d<B>& b, const Fp2d<C_>& c, const Fp2d<D>& d) {
+    return fnorm(fsub(fmul(a, b), fmul(c, d)));
+}
 // normalise once a value that is about to be used as a multiplier operand several times
 template <class P, uint32_t LA, uint32_t VA>
 MSM_HD auto fprep(const Fu<P, LA, VA>& a) {
@@ -56,6 +64,13 @@ MSM_HD auto fprep(const Fu<P, LA, VA>& a) {
 }
 template <class A>
 MSM_HD auto fprep(const Fp2u<A>& a) {
+    using C = UC<typename A::Params>;
+    if constexpr (C::cols_fit(A::LMAX, A::LMAX, A::LMAX, C::sub_cmax(A::LMAX))) return a;
+    else return fnorm(a);
+}
+
+template <class A>
+MSM_HD auto fprep(const Fp2d<A>& a) {
     using C = UC<typename A::Params>;
     if constexpr (C::cols_fit(A::LMAX, A::LMAX, A::LMAX, C::sub_cmax(A::LMAX))) return a;
     else return fnorm(a);
@@ -71,6 +86,7 @@ struct UG1 {
     using Y = FuM<P, 3>;                       // stored y: always a Montgomery output
     using M = FuM<P, 3>;                       // stored zz, zzz
     static constexpr int WORDS = P::N;         // packed words per coordinate
+    static constexpr int LANES = 1;            // lanes that share one point
     static constexpr bool INLINE_RARE = true;
     MSM_HD static In load(const uint32_t* w) { return u_from_packed<P>(w); }
     template <class T>
@@ -98,6 +114,7 @@ struct UG2 {
     using Y = Fp2u<Fu<P, UC<P>::MASK + 31, 16>>;   // a normalised lazy difference of two products
     using M = Fp2u<FuM<P, 3>>;
     static constexpr int WORDS = 2 * P::N;
+    static constexpr int LANES = 1;
     static constexpr bool INLINE_RARE = false;
     MSM_HD static In load(const uint32_t* w) { return {u_from_packed<P>(w), u_from_packed<P>(w + P::N)}; }
     template <class T>
@@ -111,6 +128,34 @@ struct UG2 {
         return {UG1<P>::template zero<typename T::Base>(), UG1<P>::template zero<typename T::Base>()};
     }
 };
+// Fp2 coordinates distributed over lane pairs (field_u.hpp, Fp2d): each lane holds one component of every coordinate.
+template <class P>
+struct UG2P {
+    using Params = P;
+    using Packed = Fp2<P>;
+    using In = Fp2d<FuIn<P>>;
+    using L = Fp2d<Fu<P, UC<P>::MASK + 31, 16>>;
+    using Y = Fp2d<Fu<P, UC<P>::MASK + 31, 16>>;
+    using M = Fp2d<FuM<P, 3>>;
+    static constexpr int WORDS = 2 * P::N;     // packed words per coordinate (both components)
+    static constexpr int LANES = 2;
+    static constexpr bool INLINE_RARE = true;
+    // w: the packed coordinate c0 || c1; this lane takes its own component
+    MSM_HD static In load(const uint32_t* w) { return {u_from_packed<P>(w + pair_parity() * P::N)}; }
+    template <class T>
+    MSM_HD static void store(uint32_t* w, const T& a) { u_to_packed(w + pair_parity() * P::N, a.v); }
+    MSM_HD static Fp2d<FuM<P, 1>> one() {
+        Fp2d<FuM<P, 1>> r;
+        const bool odd = pair_parity() != 0;
+#pragma unroll
+        for (int i = 0; i < UC<P>::NL; ++i) r.v.v[i] = odd ? 0u : P::UONE[i];
+        return r;
+    }
+    template <class T>
+    MSM_HD static T zero() {
+        return {UG1<P>::template zero<typename T::Base>()};
+    }
+};
 // which kind serves a packed coordinate field
 template <class F>
 struct UKind;
@@ -118,9 +163,16 @@ template <class P, bool INL>
 struct UKind<Fp<P, INL>> {
     using type = UG1<P>;
 };
+#ifndef MSM_G2_PAIRED
+#define MSM_G2_PAIRED 1   // 0: one lane per Fp2 point (UG2), base-field products out of line
+#endif
 template <class B>
 struct UKind<Fp2T<B>> {
+#if MSM_G2_PAIRED
+    using type = UG2P<typename B::Params>;
+#else
     using type = UG2<typename B::Params>;
+#endif
 };
 
 MSM_HD bool words_all_zero(const uint32_t* w, int n) {

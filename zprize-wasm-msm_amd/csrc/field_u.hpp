@@ -534,6 +534,94 @@ MSM_HD auto fsqr(const Fp2u<A>& a) {
 template <class A>
 MSM_HD bool fis_zero(const Fp2u<A>& a) { return fis_zero(a.c0) && fis_zero(a.c1); }
 
+
+// ------------------------------------------------------------------------------------------
+// Fp2 element DISTRIBUTED over a pair of adjacent lanes: the even lane holds c0, the odd lane c1.
+// Why: one lane per Fp2 point needs > 256 registers (one wave per SIMD, products out of line); split over two lanes
+// every value is half as wide, the code is fully inline at ~3 waves per SIMD, and a bucket is served by two lanes.
+// Component-wise operations need no communication; a product exchanges the partner's components with one DPP move
+// per limb (quad_perm [1,0,3,2]) and each lane then does ONE double-width accumulation:
+//   even lane:  c0 = a0*b0 + a1*(-b1)        odd lane:  c1 = a1*b0 + a0*b1      i.e.  own_a*U + partner_a*V.
+// Both lanes of a pair always execute the same path (every predicate below is reduced over the pair).
+// ------------------------------------------------------------------------------------------
+MSM_D uint32_t pair_parity() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return threadIdx.x & 1u;
+#else
+    return 0;
+#endif
+}
+MSM_D uint32_t pair_xchg(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+#else
+    return x;
+#endif
+}
+template <class P, uint32_t L, uint32_t V>
+MSM_D Fu<P, L, V> pair_xchg(const Fu<P, L, V>& a) {
+    Fu<P, L, V> r;
+#pragma unroll
+    for (int i = 0; i < UC<P>::NL; ++i) r.v[i] = pair_xchg(a.v[i]);
+    return r;
+}
+// odd ? b : a   (both re-typed to the looser of the two bounds)
+template <class P, uint32_t LA, uint32_t VA, uint32_t LB, uint32_t VB>
+MSM_D auto pair_select(const Fu<P, LA, VA>& a, const Fu<P, LB, VB>& b, bool odd) {
+    Fu<P, (LA > LB ? LA : LB), (VA > VB ? VA : VB)> r;
+#pragma unroll
+    for (int i = 0; i < UC<P>::NL; ++i) r.v[i] = odd ? b.v[i] : a.v[i];
+    return r;
+}
+template <class A>
+struct Fp2d {
+    using Base = A;
+    using Params = typename A::Params;
+    A v;   // this lane's component
+};
+template <class A, class B>
+MSM_D auto fadd(const Fp2d<A>& a, const Fp2d<B>& b) { auto r = fadd(a.v, b.v); return Fp2d<decltype(r)>{r}; }
+template <class A>
+MSM_D auto fdbl(const Fp2d<A>& a) { auto r = fdbl(a.v); return Fp2d<decltype(r)>{r}; }
+template <class A, class B>
+MSM_D auto fsub(const Fp2d<A>& a, const Fp2d<B>& b) { auto r = fsub(a.v, b.v); return Fp2d<decltype(r)>{r}; }
+template <class A>
+MSM_D auto fneg(const Fp2d<A>& a) { auto r = fneg(a.v); return Fp2d<decltype(r)>{r}; }
+template <class A>
+MSM_D auto fcneg(const Fp2d<A>& a, bool f) { auto r = fcneg(a.v, f); return Fp2d<decltype(r)>{r}; }
+template <class A>
+MSM_D auto fnorm(const Fp2d<A>& a) { auto r = fnorm(a.v); return Fp2d<decltype(r)>{r}; }
+template <class A, class B>
+MSM_D auto fmul(const Fp2d<A>& a, const Fp2d<B>& b) {
+    const bool odd = pair_parity() != 0;
+    const A pa = pair_xchg(a.v);
+    const B pb = pair_xchg(b.v);
+    auto U = pair_select(b.v, pb, odd);            // even: own b (b0), odd: partner b (b0)
+    auto Vv = pair_select(fneg(pb), b.v, odd);     // even: -b1,         odd: own b (b1)
+    auto r = fmul2(a.v, U, pa, Vv);
+    return Fp2d<decltype(r)>{r};
+}
+template <class A>
+MSM_D auto fsqr(const Fp2d<A>& a) {
+    using C = UC<typename A::Params>;
+    if constexpr (C::RQ >= 1024) {
+        // even: (a0 + a1)(a0 - a1),  odd: (2 a0) a1   -- one single-width product per lane
+        const bool odd = pair_parity() != 0;
+        const A pa = pair_xchg(a.v);
+        auto X = pair_select(fadd(a.v, pa), fdbl(pa), odd);
+        auto Y = pair_select(fsub(a.v, pa), a.v, odd);
+        auto r = fmul(X, Y);
+        return Fp2d<decltype(r)>{r};
+    } else {
+        return fmul(a, a);   // tight radix (BN254): the bound of (2V)(2V+1) would not close, see Fp2u::fsqr
+    }
+}
+template <class A>
+MSM_D bool fis_zero(const Fp2d<A>& a) {
+    const uint32_t z = fis_zero(a.v) ? 1u : 0u;
+    return (z & pair_xchg(z)) != 0;
+}
+
 #endif  // __HIPCC__
 
 }  // namespace msm
