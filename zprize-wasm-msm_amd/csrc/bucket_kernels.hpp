@@ -259,6 +259,11 @@ template <class F>
 size_t bucket_bytes() {
     return sizeof(BU<F>) * UKind<F>::type::LANES;
 }
+// threads that share one point (2 for the lane-paired Fp2 kind)
+template <class F>
+uint32_t lanes_per_point() {
+    return UKind<F>::type::LANES;
+}
 
 #define MSM_INSTANTIATE_ACCUMULATE(F)                                                                                                        \
     template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
@@ -267,7 +272,8 @@ size_t bucket_bytes() {
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
                                             uint32_t, void*, void*, void*, uint8_t*, uint32_t);                                              \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
-    template size_t bucket_bytes<F>();
+    template size_t bucket_bytes<F>();                                                                                                        \
+    template uint32_t lanes_per_point<F>();
 #define MSM_INSTANTIATE_BUCKET_KERNELS(F) MSM_INSTANTIATE_ACCUMULATE(F) MSM_INSTANTIATE_TAIL_AND_REDUCE(F)
 
 }  // namespace msm

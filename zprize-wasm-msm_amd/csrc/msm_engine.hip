@@ -51,6 +51,8 @@ void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, cons
 template <class F>
 size_t bucket_bytes();   // bytes of one bucket in HBM (the bucket kernels keep their own representation, curve_u.hpp)
 template <class F>
+uint32_t lanes_per_point();   // threads that share one point in the bucket kernels (2 for G2: Fp2 components on lane pairs)
+template <class F>
 struct KernelField {
     using type = F;
 };
@@ -1132,7 +1134,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
     // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
     hipStream_t sb = sl->stream_b;
-    // buckets per lane: up to 8 for a lone call (its reduction is on the critical path: short dependent chains, one wave on
+    // buckets per lane: up to 8 (16 where a point takes two threads, so that the waves still fit one per SIMD) for a lone call (its reduction is on the critical path: short dependent chains, one wave on
     // every SIMD); 32 when another call is already in flight: the reduction then hides behind that call's accumulation, and
     // what counts is its SIMD time and its register footprint -- fewer, longer lanes issue fewer instructions in total
     // (the double-and-add by the lane's first index is paid once per lane) and leave 3/4 of the SIMDs to the
@@ -1145,7 +1147,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         Plan p;
         p.L = ctx->force_L ? ctx->force_L
                            : others_pending ? std::min(32u, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
-                                            : std::min(8u, std::max(1u, (nbuckets + 65535u) / 65536u));
+                                            : std::min(8u * lanes_per_point<FK>(), std::max(1u, (nbuckets * lanes_per_point<FK>() + 65535u) / 65536u));
         p.lanes = (g.half + p.L - 1) / p.L;
         p.rblock = std::min(256u, std::max(64u, p.lanes));
         while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
