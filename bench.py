@@ -195,6 +195,13 @@ def main():
         # scatter stage (histogram + scan/order + scatter): B_scatter = 32 + 4*W per pair
         sc_ms = stages.get("histogram", 0) + stages.get("scan_order", 0) + stages.get("scatter", 0)
         sc_bytes = n * 32 + geom["entries"] * 4
+        sc_traffic = None
+        pmc_s = os.path.join(ROOT, "profiles", "pmc_scatter.json")
+        if os.path.exists(pmc_s) and (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["windows"] == 17:
+            try:
+                sc_traffic = json.load(open(pmc_s)).get("hbm_bytes_per_call")
+            except Exception:
+                sc_traffic = None
         out = {
             "metric": "BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}",
@@ -212,7 +219,10 @@ def main():
             "roofline_scatter": {"kernels": "k_histogram + scan/order + k_scatter (HBM-bound stage)", "bound": "hbm",
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
-                                 "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms},
+                                 "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,
+                                 # what the hardware counters say these kernels move (multi-pass partition: ~7x the algorithmic bytes)
+                                 "traffic": sc_traffic,
+                                 "traffic_frac_of_peak": (sc_traffic / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_ms > 0) else None},
             # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  3542 v_mad_u64_u32 per bucket
             # addition (6 products x 392 + one fused two-product reduction 588 + 2 squarings x 301, field_u.hpp) against the
             # measured full-rate peak of 36.3 T mad/s at 2.4 GHz (profiles/r01_valu_rates_microbench.txt); the mads are ~75 % of
