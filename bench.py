@@ -133,8 +133,9 @@ def main():
 
     pipelined = not args.no_pipeline and not args.host_buffers
     # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
-    # windows are sharded the accumulation per rank shrinks but the reduction latency does not, so more are needed
-    depth = 1 if not pipelined else (args.depth or (2 if world <= 2 else 4))
+    # windows are sharded 8 ways the accumulation per rank shrinks but the reduction latency does not, so more are needed
+    # (tools/bench_shard.py on one GPU: 2 in flight is best up to 4 ranks, 4 at 8 ranks)
+    depth = 1 if not pipelined else (args.depth or (2 if world <= 4 else 4))
     eng.set_option("slots", max(depth, 1))
     for kv in args.opt:
         name, val = kv.split("=")

@@ -804,9 +804,9 @@ struct msm_amd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;     // A: bucket accumulation (the ALU-bound stage), in call order
     hipStream_t stream_s = nullptr;   // S: transfers + bucket sort of the NEXT call, under the current call's accumulation
-    static constexpr uint32_t MAX_SLOTS = 4;
+    static constexpr uint32_t MAX_SLOTS = 8;
     Slot slots[MAX_SLOTS];
-    uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..4)
+    uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..8)
     uint32_t next_slot = 0;
     uint64_t next_ticket = 1;
     std::string err;
@@ -1541,7 +1541,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "slots")) {
-        if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 4]"; return MSM_AMD_EINVAL; }
+        if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 8]"; return MSM_AMD_EINVAL; }
         for (Slot& sl : ctx->slots)
             if (sl.pending) { ctx->err = "cannot change the slot count with calls in flight"; return MSM_AMD_EINVAL; }
         ctx->nslots = value;
