@@ -83,7 +83,7 @@ int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
 
 /* ---- pipelined form ------------------------------------------------------------------------------ */
 /* msm_amd_multiexp_async queues the MSM and returns a ticket; msm_amd_wait blocks until it is done and
- * writes the result.  Up to `slots` tickets (default 2, option "slots" 1..4) may be outstanding per context:
+ * writes the result.  Up to `slots` tickets (default 2, option "slots" 1..8) may be outstanding per context:
  * the engine overlaps the bucket reductions of older calls (one HIP stream per slot) with the sort and bucket
  * accumulation of the newest one (each slot has its own scratch buffers).  Inputs must stay valid and unchanged until the ticket has been waited for.
  * msm_amd_multiexp(...) == msm_amd_multiexp_async(...) + msm_amd_wait(...).                               */
