@@ -3,5 +3,5 @@
 #include "bucket_kernels.hpp"
 namespace msm {
 using F_ = Fp<Bls12381Fp, true>;
-MSM_INSTANTIATE_ACCUMULATE(F_)
+MSM_INSTANTIATE_ACCUMULATE(F_, 1)
 }  // namespace msm

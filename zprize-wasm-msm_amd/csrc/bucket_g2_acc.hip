@@ -4,6 +4,6 @@
 namespace msm {
 using F2a_ = Fp2<Bls12381Fp>;
 using F2b_ = Fp2<Bn254Fp>;
-MSM_INSTANTIATE_ACCUMULATE(F2a_)
-MSM_INSTANTIATE_ACCUMULATE(F2b_)
+MSM_INSTANTIATE_ACCUMULATE(F2a_, 0)
+MSM_INSTANTIATE_ACCUMULATE(F2b_, 0)
 }  // namespace msm

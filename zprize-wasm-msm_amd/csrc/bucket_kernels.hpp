@@ -95,7 +95,10 @@ template <class F>
 struct AccWaves {
     static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : (UKind<F>::type::LANES == 2 ? 2 : 1);
 };
-template <class F>
+// VARIANT only makes the symbols of the two builds of this kernel distinct: 1 = translation unit compiled with
+// MSM_U_CHAINED_MADS (throughput: needs >= 2-3 waves per SIMD), 0 = the compiler's two interleaved chains (a launch that
+// puts a single wave on a SIMD -- few owned windows, small n -- runs them almost twice as fast).
+template <class F, int VARIANT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                      const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
@@ -232,11 +235,16 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 
 // The accumulation kernel proper and the rest (tail kernels, reduction) are instantiated in different translation units:
 // the former is compiled with MSM_U_CHAINED_MADS (field_u.hpp), the latter -- kernels that run few waves -- without.
-template <class F>
+template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
     constexpr uint32_t T = UKind<F>::type::LANES;
-    k_accumulate<F><<<(uint32_t)(((uint64_t)nb * T + 255) / 256), 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
+#if defined(MSM_U_CHAINED_MADS)
+    static_assert(VARIANT == 1, "this translation unit builds the chained variant");
+#else
+    static_assert(VARIANT == 0, "this translation unit builds the two-chain variant");
+#endif
+    k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + 255) / 256), 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
                                                                                 (uint2*)work, (uint4*)biglist);
 }
 template <class F>
@@ -265,8 +273,8 @@ uint32_t lanes_per_point() {
     return UKind<F>::type::LANES;
 }
 
-#define MSM_INSTANTIATE_ACCUMULATE(F)                                                                                                        \
-    template void launch_accumulate<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
+#define MSM_INSTANTIATE_ACCUMULATE(F, VARIANT)                                                                                               \
+    template void launch_accumulate<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_TAIL_AND_REDUCE(F)                                                                                                   \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
@@ -274,6 +282,6 @@ uint32_t lanes_per_point() {
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
     template size_t bucket_bytes<F>();                                                                                                        \
     template uint32_t lanes_per_point<F>();
-#define MSM_INSTANTIATE_BUCKET_KERNELS(F) MSM_INSTANTIATE_ACCUMULATE(F) MSM_INSTANTIATE_TAIL_AND_REDUCE(F)
+#define MSM_INSTANTIATE_BUCKET_KERNELS(F) MSM_INSTANTIATE_ACCUMULATE(F, 0) MSM_INSTANTIATE_TAIL_AND_REDUCE(F)
 
 }  // namespace msm

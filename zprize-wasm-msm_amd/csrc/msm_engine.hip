@@ -37,7 +37,7 @@ namespace msm {
 
 
 // launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
-template <class F>
+template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
 template <class F>
@@ -55,10 +55,12 @@ uint32_t lanes_per_point();   // threads that share one point in the bucket kern
 template <class F>
 struct KernelField {
     using type = F;
+    static constexpr bool chained_variant = false;
 };
 template <class P>
 struct KernelField<Fp<P, false>> {
     using type = Fp<P, true>;
+    static constexpr bool chained_variant = true;   // bucket_g1_*_acc.hip
 };
 
 // Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
@@ -1120,14 +1122,24 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
     uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
-    launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order, split, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+    // G1 has two builds of the accumulation kernel (bucket_kernels.hpp): the chained one when the launch puts at least two waves
+    // on every SIMD, the two-chain one otherwise
+    auto accumulate = [&](const uint32_t* ord, uint32_t nbk) {
+        if constexpr (KernelField<F>::chained_variant) {
+            if ((uint64_t)nbk >= 2u * 1024u * 64u) {
+                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+                return;
+            }
+        }
+        launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+    };
+    accumulate(order, split);
     launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                                (uint8_t*)sl->d_segout.p, tail_block);
     HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
     if (split < NB) {
         HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
-        launch_accumulate<FK>(st, d_bases, d_xbeta, sorted, offset, count, order + split, NB - split, buckets, seg, sl->d_tailctl.p, sl->d_work.p,
-                              sl->d_biglist.p);
+        accumulate(order + split, NB - split);
         launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                                    (uint8_t*)sl->d_segout.p, tail_block);
     }
