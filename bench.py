@@ -174,6 +174,14 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # two more calls, one at a time and outside the timed region: stage durations without the other call's kernels
+    # running beside them (under pipelining the event intervals of a stage include whatever shares the GPU with it)
+    iso = {}
+    if pipelined and world == 1:
+        for _ in range(2):
+            step()
+            sync()
+            iso = dict(eng.timings())
     geom = eng.geometry()
     stages = {k: v / args.steps for k, v in stage_acc.items()}
 
@@ -195,6 +203,9 @@ def main():
                 traffic = None
         # scatter stage (histogram + scan/order + scatter): B_scatter = 32 + 4*W per pair
         sc_ms = stages.get("histogram", 0) + stages.get("scan_order", 0) + stages.get("scatter", 0)
+        iso_src = iso if iso else stages
+        acc_iso = iso_src.get("accumulate", 0.0)
+        sc_iso = iso_src.get("histogram", 0) + iso_src.get("scan_order", 0) + iso_src.get("scatter", 0)
         sc_bytes = n * 32 + geom["entries"] * 4
         sc_traffic = None
         pmc_s = os.path.join(ROOT, "profiles", "pmc_scatter.json")
@@ -216,22 +227,29 @@ def main():
                        "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
             "roofline": {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
+                         "avg_launch_ms_one_call_at_a_time": acc_iso,
+                         "achieved_one_call_at_a_time": (alg_bytes / (acc_iso * 1e-3) / 1e9) if acc_iso > 0 else None},
             "roofline_scatter": {"kernels": "k_histogram + scan/order + k_scatter (HBM-bound stage)", "bound": "hbm",
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,
                                  # what the hardware counters say these kernels move (multi-pass partition: ~7x the algorithmic bytes)
                                  "traffic": sc_traffic,
-                                 "traffic_frac_of_peak": (sc_traffic / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_ms > 0) else None},
+                                 "avg_ms_one_call_at_a_time": sc_iso,
+                                 "frac_one_call_at_a_time": (sc_bytes / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_iso > 0 else None,
+                                 "traffic_frac_of_peak": (sc_traffic / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_iso > 0) else None},
             # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  3542 v_mad_u64_u32 per bucket
             # addition (6 products x 392 + one fused two-product reduction 588 + 2 squarings x 301, field_u.hpp) against the
             # measured full-rate peak of 36.3 T mad/s at 2.4 GHz (profiles/r01_valu_rates_microbench.txt); the mads are ~75 % of
             # the kernel's VALU instructions (profiles/pmc_accumulate.json: SQ_INSTS_VALU) and the chip clocks this kernel
             # at ~1.95 GHz (GRBM_GUI_ACTIVE), so ~0.6 is the practical ceiling of this fraction.
             "roofline_valu": ({"kernel": "k_accumulate", "achieved": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12, "peak": 36.3, "unit": "T mad/s",
-                               "frac": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12 / 36.3} if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
+                               "frac": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12 / 36.3,
+                               "frac_one_call_at_a_time": (geom["entries"] * 3542 / (acc_iso * 1e-3) / 1e12 / 36.3) if acc_iso > 0 else None}
+                              if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
             "stages_ms": stages,
+            "stages_ms_one_call_at_a_time": iso if iso else None,
             "result_x_prefix": result[:8].hex(),
         }
         if not args.no_cpu_baseline and world == 1:
