@@ -99,6 +99,24 @@ def test_reference_kats(eng, orc):
     out = eng.curve("bls12381").g1m_multiexp_multiExp(bases, scalars, 10)    # opt-path signature
     aff = msm_amd.f_from_montgomery("bls12381", msm_amd.to_affine("bls12381", 1, out))
     assert [hex(int.from_bytes(aff[:48], "little")), hex(int.from_bytes(aff[48:], "little"))] == k["expected_affine_plain"]
+    # the chunk-level tests of the opt path (batchAffine.js:884-977, :979-1056, :1058-1175) as MSMs, whole and per chunk
+    with open(os.path.join(gu.GOLDEN, "kats_batchaffine.json")) as f:
+        sched = json.load(f)["scheduled"]
+    O = orc.Oracle("bls12381", 1)
+    C = eng.curve("bls12381")
+    for name, k in sched.items():
+        plain = b"".join(int(h, 16).to_bytes(48, "little") for h in k["points_affine_plain"])
+        bases = msm_amd.f_to_montgomery("bls12381", plain)
+        scalars = b"".join(int(h, 16).to_bytes(32, "little") for h in k["scalars"])
+        aff = msm_amd.f_from_montgomery("bls12381", msm_amd.to_affine("bls12381", 1, C.g1m_multiexpAffine(bases, scalars, 32, 10)))
+        assert [hex(int.from_bytes(aff[:48], "little")), hex(int.from_bytes(aff[48:], "little"))] == k["expected_affine_plain"], name
+        acc = O.zero()
+        for c in range(k["num_chunks"] - 1, -1, -1):
+            for _ in range(k["chunk_size"]):
+                acc = O.double(acc)
+            acc = O.add(acc, C.g1m_multiexpAffine_chunk(bases, scalars, 32, 10, c * k["chunk_size"], k["chunk_size"]))
+        aff = msm_amd.f_from_montgomery("bls12381", O.to_affine(acc))
+        assert [hex(int.from_bytes(aff[:48], "little")), hex(int.from_bytes(aff[48:], "little"))] == k["expected_affine_plain"], name
 
 
 def test_adversarial_single_bucket(eng, orc):
