@@ -151,6 +151,18 @@ int msm_amd_batch_in_curve_affine(msm_amd_ctx *ctx, int curve, int group, uint32
 int msm_amd_batch_in_group_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *points, uint32_t n,
                                   uint8_t *out_flags);
 
+/* ---- batchApplyKey (reference: wasmcurves/src/build_applykey.js:20-76 wired at
+ * bls12381/build_bls12381.js:79-92 and bn128/build_bn128.js:84-88) ------------------------------------------------------ */
+/* g?m_batchApplyKey (flag MSM_AMD_BASES_JACOBIAN: Jacobian inputs) / g?m_batchApplyKeyMixed (affine inputs), on the GPU:
+ * out[i] = (first * inc^i) * in[i], first32 / inc32 = Fr elements in Montgomery form (32 bytes LE, as frm_*).  out: n Jacobian
+ * points, NORMALISED (the reference returns some representative; compare through g?m_normalize).  MSM_AMD_DEVICE_PTRS applies
+ * to in/out.                                                                                                         */
+int msm_amd_batch_apply_key(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *in, uint32_t n,
+                            const uint8_t *first32, const uint8_t *inc32, void *out);
+/* frm_batchApplyKey: out[i] = in[i] * first * inc^i in Fr (all Montgomery, 32 bytes LE each), byte-identical to the reference. */
+int msm_amd_fr_batch_apply_key(msm_amd_ctx *ctx, int curve, uint32_t flags, const void *in, uint32_t n, const uint8_t *first32,
+                               const uint8_t *inc32, void *out);
+
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),
  * *sign bit 0 = (k1 >= 0), bit 1 = (k2 >= 0), with k = k1 + k2*lambda (mod r).  Host only.               */

@@ -48,6 +48,7 @@ typedef struct {
 } Fp;
 
 static Fp FPS[2];
+static Fp FRS[2];   /* scalar fields Fr (frm_* of the reference), same Montgomery machinery with modulus r */
 static int fps_ready = 0;
 
 /* little-endian 64-bit words */
@@ -157,6 +158,13 @@ static void ensure_init(void) {
     if (fps_ready) return;
     fp_setup(&FPS[0], 6, Q_BLS);
     fp_setup(&FPS[1], 4, Q_BN);
+    {
+        /* group orders: bls12381/build_bls12381.js:23, bn128/build_bn128.js:21 */
+        static const u64 R_BLS[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+        static const u64 R_BN[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+        fp_setup(&FRS[0], 4, R_BLS);
+        fp_setup(&FRS[1], 4, R_BN);
+    }
     fps_ready = 1;
 }
 
@@ -689,6 +697,42 @@ EXPORT int oracle_g_batch_in_group_affine(int curve, int group, const u8 *in, u3
         g_to_jacobian(&K, a, j);
         g_times_scalar(&K, j, R_BLS, 32, rp);
         flags[i] = (u8)g_is_zero(&K, rp);
+    }
+    return 0;
+}
+/* build_applykey.js:20-76 with opGtimesF = g?m_timesFr / g?m_timesFrAffine (bls12381/build_bls12381.js:79-92, :buildGTimesFr;
+ * bn128/build_bn128.js:84-88):  t = first; for i: out[i] = timesScalar(in[i], fromMontgomery(t)); t = t * inc  (Fr, Montgomery).
+ * jac_in = 1: Jacobian inputs (batchApplyKey), 0: affine inputs (batchApplyKeyMixed).  Output: Jacobian, some representative. */
+EXPORT int oracle_g_batch_apply_key(int curve, int group, int jac_in, const u8 *in, u32 n, const u8 *first, const u8 *inc, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    const Fp *R = &FRS[curve];
+    u64 t[4], incw[4], plain[4];
+    memcpy(t, first, 32); memcpy(incw, inc, 32);
+    size_t fsz = (size_t)K.nw * 8, isz = (jac_in ? 3 : 2) * fsz;
+    for (u32 i = 0; i < n; i++) {
+        u64 p[3 * MAXE], r[3 * MAXE];
+        if (jac_in) memcpy(p, in + (size_t)i * isz, isz);
+        else { u64 a[2 * MAXE]; memcpy(a, in + (size_t)i * isz, isz); g_to_jacobian(&K, a, p); }
+        fp_from_mont(R, t, plain);
+        g_times_scalar(&K, p, (const u8 *)plain, 32, r);
+        memcpy(out + (size_t)i * 3 * fsz, r, 3 * fsz);
+        fp_mul(R, t, incw, t);
+    }
+    return 0;
+}
+/* frm_batchApplyKey (build_applykey.js with opGtimesF = frm_mul): out[i] = in[i] * first * inc^i in Fr (Montgomery) */
+EXPORT int oracle_fr_batch_apply_key(int curve, const u8 *in, u32 n, const u8 *first, const u8 *inc, u8 *out) {
+    ensure_init();
+    if (curve != 0 && curve != 1) return -1;
+    const Fp *R = &FRS[curve];
+    u64 t[4], incw[4];
+    memcpy(t, first, 32); memcpy(incw, inc, 32);
+    for (u32 i = 0; i < n; i++) {
+        u64 x[4], r[4];
+        memcpy(x, in + (size_t)i * 32, 32);
+        fp_mul(R, x, t, r);
+        memcpy(out + (size_t)i * 32, r, 32);
+        fp_mul(R, t, incw, t);
     }
     return 0;
 }

@@ -137,6 +137,20 @@ class Oracle:
         assert self.L.oracle_g_batch_in_group_affine(self.cid, self.group, bytes(aff), n, out) == 0
         return list(out.raw[:n])
 
+    def batch_apply_key(self, points, first, inc, jacobian_in):
+        """g?m_batchApplyKey (jacobian_in) / g?m_batchApplyKeyMixed: raw Jacobian outputs"""
+        isz = self.jsz if jacobian_in else self.asz
+        n = len(points) // isz
+        out = _buf(max(1, n) * self.jsz)
+        assert self.L.oracle_g_batch_apply_key(self.cid, self.group, 1 if jacobian_in else 0, bytes(points), n, bytes(first), bytes(inc), out) == 0
+        return out.raw[:n * self.jsz]
+
+    def fr_batch_apply_key(self, elems, first, inc):
+        n = len(elems) // 32
+        out = _buf(max(1, n) * 32)
+        assert self.L.oracle_fr_batch_apply_key(self.cid, bytes(elems), n, bytes(first), bytes(inc), out) == 0
+        return out.raw[:n * 32]
+
     # --- field ops ---
     def f_mul(self, x, y): return self._g2("oracle_f_mul", x, y, self.fsz)
     def f_add(self, x, y): return self._g2("oracle_f_add", x, y, self.fsz)

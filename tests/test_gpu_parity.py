@@ -290,6 +290,36 @@ def test_split_window_groups(eng, orc):
         eng.set_option("split", 0)
 
 
+def test_batch_apply_key_matches_reference(eng, orc):
+    """g?m_batchApplyKey / g?m_batchApplyKeyMixed / frm_batchApplyKey on the GPU == the reference WASM (golden_applykey.json):
+    Fr elements byte for byte, group elements as normalised Jacobian points; and a longer batch against the oracle."""
+    import json
+    import os
+    with open(os.path.join(gu.GOLDEN, "golden_applykey.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        C = eng.curve(c["curve"])
+        first, inc = bytes.fromhex(c["first"]), bytes.fromhex(c["inc"])
+        assert C.frm_batchApplyKey(bytes.fromhex(c["fr_in"]), first, inc).hex() == c["fr_out"]
+        for g in (1, 2):
+            O = orc.Oracle(c["curve"], g)
+            G = c["groups"][f"g{g}"]
+            zero = O.zero()
+            for key_in, jac, key_out in (("affine_in", False, "mixed_out_norm"), ("jacobian_in", True, "jac_out_norm")):
+                got = C.batch_apply_key(g, bytes.fromhex(G[key_in]), first, inc, jac)
+                exp = bytes.fromhex(G[key_out])
+                exp = b"".join(gu.canon(c["curve"], g, exp[i * O.jsz:(i + 1) * O.jsz], zero) for i in range(G["n"]))
+                assert got == exp, (c["curve"], c["variant"], g, key_in)
+    # indices beyond the golden batch (the per-lane power inc^i): 300 points against the oracle
+    c = cases[0]
+    first, inc = bytes.fromhex(c["first"]), bytes.fromhex(c["inc"])
+    O = orc.Oracle(c["curve"], 1)
+    pts = gu.pool_points(c["curve"], 1, [i % 40 for i in range(300)])
+    raw = O.batch_apply_key(pts, first, inc, False)
+    exp = b"".join(O.normalize(raw[i * O.jsz:(i + 1) * O.jsz]) for i in range(300))
+    assert eng.curve(c["curve"]).g1m_batchApplyKeyMixed(pts, first, inc) == exp
+
+
 def test_in_group_affine_matches_reference(eng, orc):
     """Batched subgroup check on the GPU == the reference's g?m_inGroupAffine flags (golden_ingroup.json) and the oracle's."""
     import json

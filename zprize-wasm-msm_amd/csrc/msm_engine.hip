@@ -680,6 +680,115 @@ __global__ void __launch_bounds__(256) k_batch_in_curve_affine(const uint8_t* __
     flags[i] = F::sub(y2, x3b).is_zero() ? 1 : 0;
 }
 
+// ------------------------------------------------------------------------------------------
+// batchApplyKey (build_applykey.js:20-76 wired at bls12381/build_bls12381.js:79-92, bn128/build_bn128.js:84-88):
+//   out[i] = (first * inc^i) * in[i],  first / inc in Fr, Montgomery form.
+// The reference walks i sequentially (t = t * inc); here lane i raises inc to the i-th power itself (<= 2 * 27 Montgomery
+// products in Fr), leaves Montgomery form and runs a 255-step double-and-add on its own point.
+// Fr arithmetic: plain CIOS Montgomery on 8 x 32-bit limbs, always fully reduced (as frm_mul, build_f1m.js:466-777 over r).
+// ------------------------------------------------------------------------------------------
+template <class P>
+MSM_D void fr_mul(const uint32_t* a, const uint32_t* b, uint32_t* r) {
+    uint32_t t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0;
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c += (uint64_t)a[j] * b[i] + t[j];
+            t[j] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[8] = (uint32_t)c;
+        t[9] = (uint32_t)(c >> 32);
+        const uint32_t m = t[0] * P::FR_NP32;
+        c = (uint64_t)m * P::RORDER[0] + t[0];
+        c >>= 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            c += (uint64_t)m * P::RORDER[j] + t[j];
+            t[j - 1] = (uint32_t)c;
+            c >>= 32;
+        }
+        c += t[8];
+        t[7] = (uint32_t)c;
+        t[8] = t[9] + (uint32_t)(c >> 32);
+    }
+    // t < 2r: one conditional subtraction
+    uint32_t d[8];
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t v = (uint64_t)t[i] - P::RORDER[i] - br;
+        d[i] = (uint32_t)v;
+        br = (v >> 32) & 1;
+    }
+    const bool use_d = t[8] != 0 || br == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r[i] = use_d ? d[i] : t[i];
+}
+// s = first * inc^i (Montgomery)
+template <class P>
+MSM_D void fr_key(const uint32_t* first, const uint32_t* inc, uint32_t i, uint32_t* s) {
+    uint32_t e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        s[k] = first[k];
+        e[k] = inc[k];
+    }
+    while (i) {
+        if (i & 1u) fr_mul<P>(s, e, s);
+        fr_mul<P>(e, e, e);
+        i >>= 1;
+    }
+}
+template <class P>
+__global__ void __launch_bounds__(256) k_fr_batch_apply_key(const uint32_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ key, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8], x[8];
+    fr_key<P>(key, key + 8, i, s);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = in[(size_t)i * 8 + k];
+    fr_mul<P>(x, s, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[(size_t)i * 8 + k] = x[k];
+}
+template <class F, bool JAC_IN>
+__global__ void __launch_bounds__(256) k_batch_apply_key(const uint8_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ key, uint8_t* __restrict__ out) {
+    using P = typename F::Params;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p;
+    if constexpr (JAC_IN) {
+        Jacobian<F> j = load16<Jacobian<F>>(in + (size_t)i * sizeof(Jacobian<F>));
+        p = XYZZ<F>::to_affine(XYZZ<F>::from_jacobian(j));   // infinity -> (0, 0)
+    } else {
+        p = load16<Affine<F>>(in + (size_t)i * sizeof(Affine<F>));
+    }
+    uint32_t s[8], k[8];
+    fr_key<P>(key, key + 8, i, s);
+    uint32_t one[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    fr_mul<P>(s, one, k);   // frm_fromMontgomery (buildGTimesFr)
+    XYZZ<F> acc = XYZZ<F>::inf();
+    if (!p.is_inf()) {
+        for (int bit = 255; bit >= 0; --bit) {
+            acc = XYZZ<F>::dbl_ni(acc);
+            if ((k[bit >> 5] >> (bit & 31)) & 1u) XYZZ<F>::madd(acc, p.x, p.y);
+        }
+    }
+    Jacobian<F> o;
+    if (acc.is_inf()) {
+        o = {F::zero(), F::one(), F::zero()};
+    } else {
+        Affine<F> a = Affine<F>::canon(XYZZ<F>::to_affine(acc));
+        o = {a.x, a.y, F::one()};
+    }
+    store16(out + (size_t)i * sizeof(Jacobian<F>), o);
+}
+
 // bls12381/build_bls12381.js:1494-1576 / :1370-1480 (g?m_inGroupAffine), batched: 1 for affine infinity, 0 off the curve, else
 // r*P == infinity (the definition; the reference reaches the same predicate through endomorphism identities).  One lane per
 // point, 255 doublings + ~128 mixed additions; a validation pass that runs once per base table.
@@ -1441,6 +1550,50 @@ static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flag
 }
 
 
+// ---- batchApplyKey ----------------------------------------------------------------------------
+template <class F>
+static int apply_key_t(msm_amd_ctx* ctx, uint32_t flags, const void* in, uint32_t n, const uint8_t* first, const uint8_t* inc, void* out) {
+    const bool jac = (flags & MSM_AMD_BASES_JACOBIAN) != 0;
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const size_t in_b = (size_t)n * (jac ? sizeof(Jacobian<F>) : sizeof(Affine<F>)), out_b = (size_t)n * sizeof(Jacobian<F>);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *di = const_cast<void*>(in), *dout = out, *dkey = nullptr;
+    if (dev && (((uintptr_t)in & 15) || ((uintptr_t)out & 15))) {
+        ctx->err = "device pointers must be 16-byte aligned";
+        return MSM_AMD_EINVAL;
+    }
+    HIPCHK(ctx, hipMalloc(&dkey, 64));
+    hipError_t e = hipSuccess;
+    if (!dev) {
+        if (hipMalloc(&di, in_b) != hipSuccess || hipMalloc(&dout, out_b) != hipSuccess) {
+            ctx->err = "hipMalloc failed";
+            return MSM_AMD_EHIP;
+        }
+        e = hipMemcpyAsync(di, in, in_b, hipMemcpyHostToDevice, st);
+    }
+    uint8_t key[64];
+    memcpy(key, first, 32);
+    memcpy(key + 32, inc, 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(dkey, key, 64, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        if (jac) k_batch_apply_key<F, true><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (const uint32_t*)dkey, (uint8_t*)dout);
+        else k_batch_apply_key<F, false><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (const uint32_t*)dkey, (uint8_t*)dout);
+        e = hipGetLastError();
+    }
+    if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, out_b, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dkey);
+    if (!dev) {
+        (void)hipFree(di);
+        (void)hipFree(dout);
+    }
+    if (e != hipSuccess) {
+        ctx->err = std::string("batch_apply_key: ") + hipGetErrorString(e);
+        return MSM_AMD_EHIP;
+    }
+    return 0;
+}
 template <class F>
 static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* points, uint32_t n, uint8_t* out, bool group_check = false) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1674,6 +1827,66 @@ int msm_amd_batch_lem_to_u(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
 }
 int msm_amd_batch_u_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* u_in, uint32_t n, void* aff_out) {
     return conv(ctx, 3, curve, group, flags, u_in, n, aff_out);
+}
+
+int msm_amd_batch_apply_key(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* in, uint32_t n, const uint8_t* first32,
+                            const uint8_t* inc32, void* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !out || !first32 || !inc32) {
+        ctx->err = "null pointer";
+        return MSM_AMD_EINVAL;
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 1) return apply_key_t<Fp<Bls12381Fp>>(ctx, flags, in, n, first32, inc32, out);
+    if (curve == MSM_AMD_BLS12381 && group == 2) return apply_key_t<Fp2<Bls12381Fp>>(ctx, flags, in, n, first32, inc32, out);
+    if (curve == MSM_AMD_BN128 && group == 1) return apply_key_t<Fp<Bn254Fp>>(ctx, flags, in, n, first32, inc32, out);
+    if (curve == MSM_AMD_BN128 && group == 2) return apply_key_t<Fp2<Bn254Fp>>(ctx, flags, in, n, first32, inc32, out);
+    ctx->err = "unknown curve/group";
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_fr_batch_apply_key(msm_amd_ctx* ctx, int curve, uint32_t flags, const void* in, uint32_t n, const uint8_t* first32, const uint8_t* inc32,
+                               void* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !out || !first32 || !inc32 || (curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128)) {
+        ctx->err = "bad argument";
+        return MSM_AMD_EINVAL;
+    }
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const size_t bytes = (size_t)n * 32;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *di = const_cast<void*>(in), *dout = out, *dkey = nullptr;
+    HIPCHK(ctx, hipMalloc(&dkey, 64));
+    hipError_t e = hipSuccess;
+    if (!dev) {
+        if (hipMalloc(&di, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) {
+            ctx->err = "hipMalloc failed";
+            return MSM_AMD_EHIP;
+        }
+        e = hipMemcpyAsync(di, in, bytes, hipMemcpyHostToDevice, st);
+    }
+    uint8_t key[64];
+    memcpy(key, first32, 32);
+    memcpy(key + 32, inc32, 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(dkey, key, 64, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        if (curve == MSM_AMD_BLS12381) k_fr_batch_apply_key<Bls12381Fp><<<(n + 255) / 256, 256, 0, st>>>((const uint32_t*)di, n, (const uint32_t*)dkey, (uint32_t*)dout);
+        else k_fr_batch_apply_key<Bn254Fp><<<(n + 255) / 256, 256, 0, st>>>((const uint32_t*)di, n, (const uint32_t*)dkey, (uint32_t*)dout);
+        e = hipGetLastError();
+    }
+    if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(dkey);
+    if (!dev) {
+        (void)hipFree(di);
+        (void)hipFree(dout);
+    }
+    if (e != hipSuccess) {
+        ctx->err = std::string("fr_batch_apply_key: ") + hipGetErrorString(e);
+        return MSM_AMD_EHIP;
+    }
+    return 0;
 }
 
 int msm_amd_batch_in_group_affine(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* points, uint32_t n, uint8_t* out_flags) {

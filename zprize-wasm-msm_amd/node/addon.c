@@ -39,6 +39,8 @@ static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_dev_alloc)(msm_amd_ctx *, size_t, void **);
 static int (*p_dev_free)(msm_amd_ctx *, void *);
 static int (*p_h2d)(msm_amd_ctx *, void *, const void *, size_t);
+static int (*p_apply_key)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
+static int (*p_fr_apply_key)(msm_amd_ctx *, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
 static int (*p_check[2])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint8_t *);
 static int (*p_conv[4])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
@@ -78,6 +80,8 @@ static const char *load_engine(void) {
     SYM(p_dev_alloc, "msm_amd_dev_alloc")
     SYM(p_dev_free, "msm_amd_dev_free")
     SYM(p_h2d, "msm_amd_h2d")
+    SYM(p_apply_key, "msm_amd_batch_apply_key")
+    SYM(p_fr_apply_key, "msm_amd_fr_batch_apply_key")
     SYM(p_check[0], "msm_amd_batch_in_curve_affine")
     SYM(p_check[1], "msm_amd_batch_in_group_affine")
     SYM(p_conv[0], "msm_amd_batch_to_affine")
@@ -500,6 +504,40 @@ static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
     return res;
 }
 
+/* ---- batchApplyKey(ctx, curve, group 0 = Fr | 1 | 2, jacobianIn 0/1, Uint8Array in, Uint8Array first(32), Uint8Array inc(32))
+ *      -> Uint8Array: n normalised Jacobian points (group 1/2) or n Fr elements (group 0)  (build_applykey.js:20-76) ---- */
+static napi_value js_batch_apply_key(napi_env env, napi_callback_info info) {
+    size_t argc = 7;
+    napi_value argv[7];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int curve, group, jac;
+    const uint8_t *in, *first, *inc;
+    size_t lin, lf, li;
+    if (argc < 7 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &curve) || get_i32(env, argv[2], &group) ||
+        get_i32(env, argv[3], &jac) || get_bytes(env, argv[4], &in, &lin) || get_bytes(env, argv[5], &first, &lf) || get_bytes(env, argv[6], &inc, &li) ||
+        (curve != 0 && curve != 1) || group < 0 || group > 2 || lf < 32 || li < 32) {
+        napi_throw_type_error(env, NULL, "batchApplyKey(ctx, curve, group 0..2, jacobianIn, Uint8Array in, first: Uint8Array(32), inc: Uint8Array(32))");
+        return NULL;
+    }
+    size_t fsz = (size_t)n8_of(curve) * (group ? group : 1);
+    size_t in_sz = group == 0 ? 32 : (jac ? 3 : 2) * fsz, out_sz = group == 0 ? 32 : 3 * fsz;
+    if (lin % in_sz) {
+        napi_throw_range_error(env, NULL, "input is not a whole number of elements");
+        return NULL;
+    }
+    uint32_t n = (uint32_t)(lin / in_sz);
+    uint8_t *out = (uint8_t *)malloc((size_t)n * out_sz + 1);
+    if (!out) return NULL;
+    int rc = group == 0 ? p_fr_apply_key((msm_amd_ctx *)ctx, curve, 0, in, n, first, inc, out)
+                        : p_apply_key((msm_amd_ctx *)ctx, curve, group, jac ? MSM_AMD_BASES_JACOBIAN : 0, in, n, first, inc, out);
+    napi_value res = NULL;
+    if (rc) napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+    else res = bytes_out(env, out, (size_t)n * out_sz);
+    free(out);
+    return res;
+}
+
 /* ---- point validation: batchCheck(ctx, which 0 = inCurveAffine | 1 = inGroupAffine, curve, group, Uint8Array affine points)
  *      -> Uint8Array of 0/1 flags (g?m_inCurveAffine, build_curve_jacobian_a0.js:1330-1353; g?m_inGroupAffine, bls12381 only) ---- */
 static napi_value js_batch_check(napi_env env, napi_callback_info info) {
@@ -633,6 +671,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"multiexpResident", NULL, js_multiexp_resident, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchCheck", NULL, js_batch_check, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"batchApplyKey", NULL, js_batch_apply_key, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvPreprocess", NULL, js_glv_preprocess, NULL, NULL, NULL, napi_enumerable, NULL},

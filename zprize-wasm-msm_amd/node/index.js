@@ -48,6 +48,8 @@ function instantiate(curveName, imports, opts) {
     const ctx = context(opts && opts.device);
     const u8 = () => new Uint8Array(memory.buffer);
     const ex = { memory };
+    ex.frm_batchApplyKey = (pIn, n, pFirst, pInc, pOut) => u8().set(native.batchApplyKey(ctx, C.id, 0, 0, u8().subarray(pIn, pIn + n * 32),
+        u8().subarray(pFirst, pFirst + 32), u8().subarray(pInc, pInc + 32)), pOut);
     for (const g of [1, 2]) {
         const pf = `g${g}m`;
         const fsz = C.n8 * g;
@@ -74,6 +76,11 @@ function instantiate(curveName, imports, opts) {
             ex[`${pf}_inGroupAffine`] = (p) => native.batchCheck(ctx, 1, C.id, g, u8().subarray(p, p + 2 * fsz))[0];
             ex[`${pf}_batchInGroupAffine`] = (pIn, n) => native.batchCheck(ctx, 1, C.id, g, u8().subarray(pIn, pIn + n * 2 * fsz));
         }
+        // out[i] = (first * inc^i) * in[i]; (pIn, n, pFirst, pInc, pOut) as the reference's exports; output normalised Jacobian
+        const applyKey = (jacIn) => (pIn, n, pFirst, pInc, pOut) => u8().set(native.batchApplyKey(ctx, C.id, g, jacIn, u8().subarray(pIn, pIn + n * (jacIn ? 3 : 2) * fsz),
+            u8().subarray(pFirst, pFirst + 32), u8().subarray(pInc, pInc + 32)), pOut);
+        ex[`${pf}_batchApplyKey`] = applyKey(1);
+        ex[`${pf}_batchApplyKeyMixed`] = applyKey(0);
         ex[`${pf}_batchToAffine`] = conv(0, 3 * fsz, 2 * fsz);
         ex[`${pf}_batchToJacobian`] = conv(1, 2 * fsz, 3 * fsz);
         ex[`${pf}_batchLEMtoU`] = conv(2, 2 * fsz, 2 * fsz);

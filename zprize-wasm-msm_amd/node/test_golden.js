@@ -130,6 +130,34 @@ async function main() {
             checked += 2;
         }
     }
+    // batchApplyKey (tests/golden/golden_applykey.json) through the export-shaped surface
+    if (!hostOnly) {
+        const ak = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_applykey.json")));
+        for (const c of ak.cases) {
+            const memory = new WebAssembly.Memory({ initial: 8 });
+            const m = msm.instantiate(c.curve, { memory });
+            const mem = () => new Uint8Array(memory.buffer);
+            const pFirst = 1024, pInc = 1056, pIn = 2048;
+            mem().set(Buffer.from(c.first, "hex"), pFirst); mem().set(Buffer.from(c.inc, "hex"), pInc);
+            const frIn = Buffer.from(c.fr_in, "hex");
+            mem().set(frIn, pIn);
+            const pOut = pIn + 65536;
+            m.frm_batchApplyKey(pIn, c.fr_n, pFirst, pInc, pOut);
+            if (Buffer.from(mem().slice(pOut, pOut + frIn.length)).toString("hex") !== c.fr_out) throw new Error("frm_batchApplyKey differs");
+            for (const g of [1, 2]) {
+                const G = c.groups[`g${g}`], pf = `g${g}m`, fsz = (c.curve === "bls12381" ? 48 : 32) * g,
+                    zeroHex = Buffer.from(msm.native.combine(c.curve === "bls12381" ? 0 : 1, g, new Uint8Array(0))).toString("hex");
+                const aff = Buffer.from(G.affine_in, "hex");
+                mem().set(aff, pIn);
+                m[`${pf}_batchApplyKeyMixed`](pIn, G.n, pFirst, pInc, pOut);
+                const got = Buffer.from(mem().slice(pOut, pOut + G.n * 3 * fsz)).toString("hex");
+                let exp = "";
+                for (let i = 0; i < G.n; i++) exp += canon(G.mixed_out_norm.slice(i * 6 * fsz, (i + 1) * 6 * fsz), fsz, zeroHex);
+                if (got !== exp) throw new Error(`${pf}_batchApplyKeyMixed differs (${c.curve} ${c.variant})`);
+            }
+            checked += 3;
+        }
+    }
     // GLV: the reference's known answer (wasmcurves/test/glv.js:50-65) through the export-shaped surface
     {
         const kat = JSON.parse(fs.readFileSync(path.join(GOLD, "kats_glv.json")));

@@ -70,6 +70,8 @@ def load_library(path=None):
         getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_curve_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_group_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_batch_apply_key.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp, vp, vp]
+    L.msm_amd_fr_batch_apply_key.argtypes = [vp, c.c_int, u32, vp, u32, vp, vp, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_split.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
@@ -304,6 +306,28 @@ class Curve:
         out = ctypes.create_string_buffer(max(1, n))
         self.eng._chk(self.eng.L.msm_amd_batch_in_curve_affine(self.eng.ctx, self.cid, group, 0, points, n, out))
         return list(out.raw[:n])
+
+    def batch_apply_key(self, group, points, first, inc, jacobian_in=False):
+        """g?m_batchApplyKey (jacobian_in) / g?m_batchApplyKeyMixed: n normalised Jacobian points"""
+        points = bytes(points)
+        isz = self.jacobian_bytes(group) if jacobian_in else self.affine_bytes(group)
+        n = len(points) // isz
+        out = ctypes.create_string_buffer(max(1, n) * self.jacobian_bytes(group))
+        self.eng._chk(self.eng.L.msm_amd_batch_apply_key(self.eng.ctx, self.cid, group, FLAG_JACOBIAN if jacobian_in else 0, points, n,
+                                                          bytes(first), bytes(inc), out))
+        return out.raw[:n * self.jacobian_bytes(group)]
+
+    def g1m_batchApplyKey(self, jac, first, inc): return self.batch_apply_key(1, jac, first, inc, True)
+    def g1m_batchApplyKeyMixed(self, aff, first, inc): return self.batch_apply_key(1, aff, first, inc, False)
+    def g2m_batchApplyKey(self, jac, first, inc): return self.batch_apply_key(2, jac, first, inc, True)
+    def g2m_batchApplyKeyMixed(self, aff, first, inc): return self.batch_apply_key(2, aff, first, inc, False)
+
+    def frm_batchApplyKey(self, elems, first, inc):
+        elems = bytes(elems)
+        n = len(elems) // 32
+        out = ctypes.create_string_buffer(max(1, n) * 32)
+        self.eng._chk(self.eng.L.msm_amd_fr_batch_apply_key(self.eng.ctx, self.cid, 0, elems, n, bytes(first), bytes(inc), out))
+        return out.raw[:n * 32]
 
     def batch_in_group_affine(self, group, points):
         """g?m_inGroupAffine over a batch (bls12381 only): list of 0/1 flags"""
