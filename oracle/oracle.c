@@ -736,6 +736,118 @@ EXPORT int oracle_fr_batch_apply_key(int curve, const u8 *in, u32 n, const u8 *f
     }
     return 0;
 }
+/* build_fft.js:23-68: roots of unity of Fr.  maxBits = 2-adicity of r-1, nr = smallest quadratic non-residue >= 2,
+ * w[maxBits] = nr^((r-1)/2^maxBits), w[s] = w[s+1]^2; INV2[b] = 2^-b.  All kept in Montgomery form. */
+static void fr_pow(const Fp *R, const u64 *base, const u64 *e, int ewords, u64 *r) {
+    u64 acc[4], b[4];
+    memcpy(acc, R->one, 32); memcpy(b, base, 32);
+    for (int i = 0; i < ewords * 64; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) fp_mul(R, acc, b, acc);
+        fp_mul(R, b, b, b);
+    }
+    memcpy(r, acc, 32);
+}
+static int fr_roots(int curve, u64 roots[33][4], u64 *inv2pow /* [33][4] */) {
+    const Fp *R = &FRS[curve];
+    u64 rem[4], one_plain[4] = {1, 0, 0, 0}, half[4];
+    memcpy(rem, R->q, 32); rem[0] -= 1;   /* r - 1 */
+    int maxbits = 0;
+    while (!(rem[0] & 1)) { for (int i = 0; i < 4; i++) rem[i] = (rem[i] >> 1) | (i < 3 ? rem[i + 1] << 63 : 0); maxbits++; }
+    /* (r-1)/2 for the Euler criterion */
+    memcpy(half, R->q, 32); half[0] -= 1;
+    for (int i = 0; i < 4; i++) half[i] = (half[i] >> 1) | (i < 3 ? half[i + 1] << 63 : 0);
+    u64 nr_plain[4] = {2, 0, 0, 0}, nr[4], t[4];
+    for (;;) {
+        fp_to_mont(R, nr_plain, nr);
+        fr_pow(R, nr, half, 4, t);
+        if (!int_eq(4, t, R->one)) break;
+        nr_plain[0]++;
+    }
+    (void)one_plain;
+    fr_pow(R, nr, rem, 4, roots[maxbits]);
+    for (int s = maxbits - 1; s >= 0; s--) fp_mul(R, roots[s + 1], roots[s + 1], roots[s]);
+    /* 2^-b: (r+1)/2 is 1/2 */
+    u64 h_plain[4], h[4];
+    memcpy(h_plain, R->q, 32);
+    { u128 c = 1; for (int i = 0; i < 4; i++) { c += h_plain[i]; h_plain[i] = (u64)c; c >>= 64; } }
+    for (int i = 0; i < 4; i++) h_plain[i] = (h_plain[i] >> 1) | (i < 3 ? h_plain[i + 1] << 63 : 0);
+    fp_to_mont(R, h_plain, h);
+    memcpy(inv2pow, R->one, 32);
+    for (int b = 1; b <= maxbits; b++) fp_mul(R, inv2pow + 4 * (b - 1), h, inv2pow + 4 * b);
+    return maxbits;
+}
+static u32 bitrev(u32 x, int bits) { u32 r = 0; for (int i = 0; i < bits; i++) if (x & (1u << i)) r |= 1u << (bits - 1 - i); return r; }
+/* frm_fft / frm_ifft (build_fft.js:178-245 -> rawfft :247-394 -> fftFinal :396-516): bit-reversal permutation, log2 n stages of
+ * butterflies (u, t = W*x2) -> (u + t, u - t) with W running over the powers of ROOTs[s]; the inverse transform is the forward one
+ * followed by out[i] = x[(n - i) mod n] * 2^-bits.  Elements: Fr in Montgomery form; in place semantics, here in -> out. */
+EXPORT int oracle_fr_fft(int curve, int inverse, const u8 *in, u32 n, u8 *out) {
+    ensure_init();
+    if ((curve != 0 && curve != 1) || n == 0 || (n & (n - 1))) return -1;
+    const Fp *R = &FRS[curve];
+    static u64 roots[2][33][4], inv2[2][33 * 4]; static int mb[2] = {0, 0};
+    if (!mb[curve]) mb[curve] = fr_roots(curve, roots[curve], inv2[curve]);
+    int bits = 0; while ((1u << bits) < n) bits++;
+    if (bits > mb[curve]) return -1;
+    u64 *x = (u64 *)malloc((size_t)n * 32);
+    for (u32 i = 0; i < n; i++) memcpy(x + 4 * (size_t)bitrev(i, bits), in + (size_t)i * 32, 32);
+    for (int s = 1; s <= bits; s++) {
+        u32 m = 1u << s, h = m >> 1;
+        for (u32 k = 0; k < n; k += m) {
+            u64 w[4]; memcpy(w, R->one, 32);
+            for (u32 j = 0; j < h; j++) {
+                u64 *a = x + 4 * (size_t)(k + j), *b = x + 4 * (size_t)(k + j + h), t[4], u[4];
+                fp_mul(R, b, w, t); memcpy(u, a, 32);
+                fp_add(R, u, t, a); fp_sub(R, u, t, b);
+                fp_mul(R, w, roots[curve][s], w);
+            }
+        }
+    }
+    for (u32 i = 0; i < n; i++) {
+        const u64 *src = inverse ? x + 4 * (size_t)((n - i) & (n - 1)) : x + 4 * (size_t)i;
+        u64 r[4];
+        if (inverse) fp_mul(R, src, inv2[curve] + 4 * bits, r); else memcpy(r, src, 32);
+        memcpy(out + (size_t)i * 32, r, 32);
+    }
+    free(x);
+    return 0;
+}
+/* g?m_fft / g?m_ifft: the same transform over Jacobian points, W*x2 through g?m_timesFr (fromMontgomery, then timesScalar) */
+EXPORT int oracle_g_fft(int curve, int group, int inverse, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    if (n == 0 || (n & (n - 1))) return -1;
+    const Fp *R = &FRS[curve];
+    static u64 roots[2][33][4], inv2[2][33 * 4]; static int mb[2] = {0, 0};
+    if (!mb[curve]) mb[curve] = fr_roots(curve, roots[curve], inv2[curve]);
+    int bits = 0; while ((1u << bits) < n) bits++;
+    if (bits > mb[curve]) return -1;
+    size_t jw = 3 * (size_t)K.nw, jsz = jw * 8;
+    u64 *x = (u64 *)malloc((size_t)n * jsz);
+    for (u32 i = 0; i < n; i++) memcpy(x + jw * bitrev(i, bits), in + (size_t)i * jsz, jsz);
+    for (int s = 1; s <= bits; s++) {
+        u32 m = 1u << s, h = m >> 1;
+        for (u32 k = 0; k < n; k += m) {
+            u64 w[4]; memcpy(w, R->one, 32);
+            for (u32 j = 0; j < h; j++) {
+                u64 *a = x + jw * (k + j), *b = x + jw * (k + j + h), t[3 * MAXE], u[3 * MAXE], nt[3 * MAXE], plain[4];
+                fp_from_mont(R, w, plain);
+                g_times_scalar(&K, b, (const u8 *)plain, 32, t);
+                g_copy(&K, a, u);
+                g_add(&K, u, t, a);
+                g_neg(&K, t, nt); g_add(&K, u, nt, b);
+                fp_mul(R, w, roots[curve][s], w);
+            }
+        }
+    }
+    for (u32 i = 0; i < n; i++) {
+        const u64 *src = inverse ? x + jw * ((n - i) & (n - 1)) : x + jw * i;
+        u64 r[3 * MAXE];
+        if (inverse) { u64 plain[4]; fp_from_mont(R, inv2[curve] + 4 * bits, plain); g_times_scalar(&K, src, (const u8 *)plain, 32, r); }
+        else g_copy(&K, src, r);
+        memcpy(out + (size_t)i * jsz, r, jsz);
+    }
+    free(x);
+    return 0;
+}
 static void reverse_bytes(const u8 *in, size_t n, u8 *out) { for (size_t i = 0; i < n; i++) out[i] = in[n - 1 - i]; }
 /* build_curve_jacobian_a0.js:1206-1231,1413 (LEMtoU / batchLEMtoU): affine little-endian Montgomery ->
  * x || y big-endian plain; infinity -> zeros with first byte 0x40 */

@@ -151,6 +151,18 @@ class Oracle:
         assert self.L.oracle_fr_batch_apply_key(self.cid, bytes(elems), n, bytes(first), bytes(inc), out) == 0
         return out.raw[:n * 32]
 
+    def fr_fft(self, elems, inverse=False):
+        n = len(elems) // 32
+        out = _buf(max(1, n) * 32)
+        assert self.L.oracle_fr_fft(self.cid, 1 if inverse else 0, bytes(elems), n, out) == 0
+        return out.raw[:n * 32]
+
+    def g_fft(self, jac, inverse=False):
+        n = len(jac) // self.jsz
+        out = _buf(max(1, n) * self.jsz)
+        assert self.L.oracle_g_fft(self.cid, self.group, 1 if inverse else 0, bytes(jac), n, out) == 0
+        return out.raw[:n * self.jsz]
+
     # --- field ops ---
     def f_mul(self, x, y): return self._g2("oracle_f_mul", x, y, self.fsz)
     def f_add(self, x, y): return self._g2("oracle_f_add", x, y, self.fsz)
