@@ -48,6 +48,7 @@ enum { MSM_AMD_BLS12381 = 0, MSM_AMD_BN128 = 1 };
 enum {
     MSM_AMD_BASES_JACOBIAN = 1, /* bases are X||Y||Z (g?m_multiexp); default affine x||y (g?m_multiexpAffine) */
     MSM_AMD_DEVICE_PTRS = 2,    /* bases and scalars already live in this context's GPU memory              */
+    MSM_AMD_FFT_INVERSE = 8,    /* msm_amd_fft: the inverse transform (g?m_ifft / frm_ifft)                                */
     MSM_AMD_DEVICE_BASES = 4    /* only the bases are resident on the GPU (msm_amd_dev_alloc + msm_amd_h2d once: the fixed
                                    SRS of a prover); the scalars are a host buffer copied over PCIe by every call    */
 };
@@ -162,6 +163,12 @@ int msm_amd_batch_apply_key(msm_amd_ctx *ctx, int curve, int group, uint32_t fla
 /* frm_batchApplyKey: out[i] = in[i] * first * inc^i in Fr (all Montgomery, 32 bytes LE each), byte-identical to the reference. */
 int msm_amd_fr_batch_apply_key(msm_amd_ctx *ctx, int curve, uint32_t flags, const void *in, uint32_t n, const uint8_t *first32,
                                const uint8_t *inc32, void *out);
+
+/* frm_fft / frm_ifft (group = 0: n Fr elements, Montgomery, 32 bytes each; byte-identical to the reference) and g1m_/g2m_ fft /
+ * ifft (group = 1 / 2: n Jacobian points in, n NORMALISED Jacobian points out) -- wasmcurves/src/build_fft.js:178-245 (fft, ifft),
+ * :247-394 (rawfft), :396-516 (fftFinal), roots of unity :33-50.  n a power of two <= 2^27; flags: MSM_AMD_FFT_INVERSE,
+ * MSM_AMD_DEVICE_PTRS.  The reference transforms in place; here in -> out (they may be the same buffer).           */
+int msm_amd_fft(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *in, uint32_t n, void *out);
 
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),

@@ -320,6 +320,40 @@ def test_batch_apply_key_matches_reference(eng, orc):
     assert eng.curve(c["curve"]).g1m_batchApplyKeyMixed(pts, first, inc) == exp
 
 
+def test_fft_matches_reference(eng, orc):
+    """frm_fft / frm_ifft byte for byte and g?m_fft / g?m_ifft as normalised points == the reference WASM (golden_fft.json); a
+    larger Fr transform against the oracle and a round trip at 2^16."""
+    import json
+    import os
+    with open(os.path.join(gu.GOLDEN, "golden_fft.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        C = eng.curve(c["curve"])
+        inp = bytes.fromhex(c["in"])
+        if c["group"] == 0:
+            assert C.frm_fft(inp).hex() == c["fft"], (c["curve"], c["n"])
+            assert C.frm_ifft(inp).hex() == c["ifft"], (c["curve"], c["n"])
+        else:
+            O = orc.Oracle(c["curve"], c["group"])
+            zero = O.zero()
+            for inv, key in ((False, "fft"), (True, "ifft")):
+                exp = bytes.fromhex(c[key])
+                exp = b"".join(gu.canon(c["curve"], c["group"], exp[i * O.jsz:(i + 1) * O.jsz], zero) for i in range(c["n"]))
+                assert C.fft(c["group"], inp, inv) == exp, (c["curve"], c["group"], c["n"], key)
+    for curve in CURVES:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, 1)
+        r = gu.R_ORDER[curve]
+        raw = gu.stream(f"gpu:fft:{curve}", 40 * 4096)
+        plain = b"".join((int.from_bytes(raw[40 * i:40 * i + 40], "little") % r).to_bytes(32, "little") for i in range(4096))
+        assert C.frm_fft(plain) == O.fr_fft(plain)
+        assert C.frm_ifft(plain) == O.fr_fft(plain, True)
+        big = plain * 16                                                    # 2^16 elements
+        assert C.frm_ifft(C.frm_fft(big)) == big
+    with pytest.raises(Exception):
+        eng.curve("bls12381").frm_fft(bytes(32 * 3))                         # not a power of two
+
+
 def test_in_group_affine_matches_reference(eng, orc):
     """Batched subgroup check on the GPU == the reference's g?m_inGroupAffine flags (golden_ingroup.json) and the oracle's."""
     import json

@@ -39,6 +39,7 @@ static int (*p_f_from_m)(int, const uint8_t *, uint32_t, uint8_t *);
 static int (*p_dev_alloc)(msm_amd_ctx *, size_t, void **);
 static int (*p_dev_free)(msm_amd_ctx *, void *);
 static int (*p_h2d)(msm_amd_ctx *, void *, const void *, size_t);
+static int (*p_fft)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_apply_key)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
 static int (*p_fr_apply_key)(msm_amd_ctx *, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
 static int (*p_check[2])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint8_t *);
@@ -80,6 +81,7 @@ static const char *load_engine(void) {
     SYM(p_dev_alloc, "msm_amd_dev_alloc")
     SYM(p_dev_free, "msm_amd_dev_free")
     SYM(p_h2d, "msm_amd_h2d")
+    SYM(p_fft, "msm_amd_fft")
     SYM(p_apply_key, "msm_amd_batch_apply_key")
     SYM(p_fr_apply_key, "msm_amd_fr_batch_apply_key")
     SYM(p_check[0], "msm_amd_batch_in_curve_affine")
@@ -504,6 +506,36 @@ static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
     return res;
 }
 
+/* ---- fft(ctx, curve, group 0 = Fr | 1 | 2, inverse 0/1, Uint8Array data) -> Uint8Array  (build_fft.js:178-245) ---- */
+static napi_value js_fft(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int curve, group, inverse;
+    const uint8_t *in;
+    size_t lin;
+    if (argc < 5 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &curve) || get_i32(env, argv[2], &group) ||
+        get_i32(env, argv[3], &inverse) || get_bytes(env, argv[4], &in, &lin) || (curve != 0 && curve != 1) || group < 0 || group > 2) {
+        napi_throw_type_error(env, NULL, "fft(ctx, curve, group 0..2, inverse, Uint8Array)");
+        return NULL;
+    }
+    size_t esz = group == 0 ? 32 : (size_t)3 * n8_of(curve) * group;
+    if (lin % esz) {
+        napi_throw_range_error(env, NULL, "input is not a whole number of elements");
+        return NULL;
+    }
+    uint32_t n = (uint32_t)(lin / esz);
+    uint8_t *out = (uint8_t *)malloc((size_t)n * esz + 1);
+    if (!out) return NULL;
+    int rc = p_fft((msm_amd_ctx *)ctx, curve, group, inverse ? MSM_AMD_FFT_INVERSE : 0, in, n, out);
+    napi_value res = NULL;
+    if (rc) napi_throw_error(env, "MSM_AMD_ERROR", p_last_error((msm_amd_ctx *)ctx));
+    else res = bytes_out(env, out, (size_t)n * esz);
+    free(out);
+    return res;
+}
+
 /* ---- batchApplyKey(ctx, curve, group 0 = Fr | 1 | 2, jacobianIn 0/1, Uint8Array in, Uint8Array first(32), Uint8Array inc(32))
  *      -> Uint8Array: n normalised Jacobian points (group 1/2) or n Fr elements (group 0)  (build_applykey.js:20-76) ---- */
 static napi_value js_batch_apply_key(napi_env env, napi_callback_info info) {
@@ -672,6 +704,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchCheck", NULL, js_batch_check, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchApplyKey", NULL, js_batch_apply_key, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"fft", NULL, js_fft, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvDecomposeScalar", NULL, js_glv_decompose, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvEndomorphism", NULL, js_glv_endomorphism, NULL, NULL, NULL, napi_enumerable, NULL},
         {"glvPreprocess", NULL, js_glv_preprocess, NULL, NULL, NULL, napi_enumerable, NULL},

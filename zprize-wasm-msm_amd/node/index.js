@@ -48,6 +48,10 @@ function instantiate(curveName, imports, opts) {
     const ctx = context(opts && opts.device);
     const u8 = () => new Uint8Array(memory.buffer);
     const ex = { memory };
+    // in-place transforms, (p, n) as the reference's exports (build_fft.js:178-245); group results are normalised Jacobian points
+    const fftFn = (grp, esz, inverse) => (p, n) => u8().set(native.fft(ctx, C.id, grp, inverse, u8().subarray(p, p + n * esz)), p);
+    ex.frm_fft = fftFn(0, 32, 0);
+    ex.frm_ifft = fftFn(0, 32, 1);
     ex.frm_batchApplyKey = (pIn, n, pFirst, pInc, pOut) => u8().set(native.batchApplyKey(ctx, C.id, 0, 0, u8().subarray(pIn, pIn + n * 32),
         u8().subarray(pFirst, pFirst + 32), u8().subarray(pInc, pInc + 32)), pOut);
     for (const g of [1, 2]) {
@@ -79,6 +83,8 @@ function instantiate(curveName, imports, opts) {
         // out[i] = (first * inc^i) * in[i]; (pIn, n, pFirst, pInc, pOut) as the reference's exports; output normalised Jacobian
         const applyKey = (jacIn) => (pIn, n, pFirst, pInc, pOut) => u8().set(native.batchApplyKey(ctx, C.id, g, jacIn, u8().subarray(pIn, pIn + n * (jacIn ? 3 : 2) * fsz),
             u8().subarray(pFirst, pFirst + 32), u8().subarray(pInc, pInc + 32)), pOut);
+        ex[`${pf}_fft`] = fftFn(g, 3 * fsz, 0);
+        ex[`${pf}_ifft`] = fftFn(g, 3 * fsz, 1);
         ex[`${pf}_batchApplyKey`] = applyKey(1);
         ex[`${pf}_batchApplyKeyMixed`] = applyKey(0);
         ex[`${pf}_batchToAffine`] = conv(0, 3 * fsz, 2 * fsz);

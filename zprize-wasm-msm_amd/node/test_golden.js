@@ -130,6 +130,32 @@ async function main() {
             checked += 2;
         }
     }
+    // FFTs (tests/golden/golden_fft.json), in place through the export-shaped surface
+    if (!hostOnly) {
+        const ff = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_fft.json")));
+        for (const c of ff.cases) {
+            if (c.group !== 0 && c.n > 8) continue;
+            const memory = new WebAssembly.Memory({ initial: 8 });
+            const m = msm.instantiate(c.curve, { memory });
+            const mem = () => new Uint8Array(memory.buffer);
+            const inp = Buffer.from(c.in, "hex"), p = 4096;
+            const pf = c.group === 0 ? "frm" : `g${c.group}m`;
+            for (const [fn, key] of [["fft", "fft"], ["ifft", "ifft"]]) {
+                mem().set(inp, p);
+                m[`${pf}_${fn}`](p, c.n);
+                const got = Buffer.from(mem().slice(p, p + inp.length)).toString("hex");
+                let exp = c[key];
+                if (c.group !== 0) {
+                    const fsz = (c.curve === "bls12381" ? 48 : 32) * c.group;
+                    const zeroHex = Buffer.from(msm.native.combine(c.curve === "bls12381" ? 0 : 1, c.group, new Uint8Array(0))).toString("hex");
+                    exp = "";
+                    for (let i = 0; i < c.n; i++) exp += canon(c[key].slice(i * 6 * fsz, (i + 1) * 6 * fsz), fsz, zeroHex);
+                }
+                if (got !== exp) throw new Error(`${pf}_${fn} differs (${c.curve} n=${c.n})`);
+            }
+            checked += 2;
+        }
+    }
     // batchApplyKey (tests/golden/golden_applykey.json) through the export-shaped surface
     if (!hostOnly) {
         const ak = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_applykey.json")));

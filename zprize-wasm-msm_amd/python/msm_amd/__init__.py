@@ -26,6 +26,7 @@ N8 = {"bls12381": 48, "bn128": 32}
 FLAG_JACOBIAN = 1
 FLAG_DEVICE = 2
 FLAG_DEVICE_BASES = 4
+FLAG_FFT_INVERSE = 8
 
 
 class MsmAmdError(RuntimeError):
@@ -72,6 +73,7 @@ def load_library(path=None):
     L.msm_amd_batch_in_group_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_apply_key.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp, vp, vp]
     L.msm_amd_fr_batch_apply_key.argtypes = [vp, c.c_int, u32, vp, u32, vp, vp, vp]
+    L.msm_amd_fft.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_split.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
@@ -328,6 +330,22 @@ class Curve:
         out = ctypes.create_string_buffer(max(1, n) * 32)
         self.eng._chk(self.eng.L.msm_amd_fr_batch_apply_key(self.eng.ctx, self.cid, 0, elems, n, bytes(first), bytes(inc), out))
         return out.raw[:n * 32]
+
+    def fft(self, group, data, inverse=False):
+        """frm_fft / frm_ifft (group 0: Fr elements) or g?m_fft / g?m_ifft (Jacobian points in, normalised Jacobian out)"""
+        data = bytes(data)
+        esz = 32 if group == 0 else self.jacobian_bytes(group)
+        n = len(data) // esz
+        out = ctypes.create_string_buffer(max(1, n) * esz)
+        self.eng._chk(self.eng.L.msm_amd_fft(self.eng.ctx, self.cid, group, FLAG_FFT_INVERSE if inverse else 0, data, n, out))
+        return out.raw[:n * esz]
+
+    def frm_fft(self, elems): return self.fft(0, elems)
+    def frm_ifft(self, elems): return self.fft(0, elems, True)
+    def g1m_fft(self, jac): return self.fft(1, jac)
+    def g1m_ifft(self, jac): return self.fft(1, jac, True)
+    def g2m_fft(self, jac): return self.fft(2, jac)
+    def g2m_ifft(self, jac): return self.fft(2, jac, True)
 
     def batch_in_group_affine(self, group, points):
         """g?m_inGroupAffine over a batch (bls12381 only): list of 0/1 flags"""
