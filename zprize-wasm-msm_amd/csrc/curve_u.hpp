@@ -305,8 +305,19 @@ struct XYZZU {
         r.zzz = fstore<typename K::M>(fmul(fmul(a.zzz, b.zzz), PPP));
         return r;
     }
-    __host__ __device__ __noinline__ static XYZZU add_ni(XYZZU a, XYZZU b) { return add(a, b); }
-    __host__ __device__ __noinline__ static XYZZU dbl_ni(XYZZU a) { return dbl(a); }
+    // out-of-line forms; operands by reference (two large by-value structs were seen to arrive corrupted in a callee)
+    __host__ __device__ __noinline__ static void add_to(XYZZU& r, const XYZZU& a, const XYZZU& b) { r = add(a, b); }
+    __host__ __device__ __noinline__ static void dbl_to(XYZZU& r, const XYZZU& a) { r = dbl(a); }
+    MSM_HD static XYZZU add_ni(const XYZZU& a, const XYZZU& b) {
+        XYZZU r;
+        add_to(r, a, b);
+        return r;
+    }
+    MSM_HD static XYZZU dbl_ni(const XYZZU& a) {
+        XYZZU r;
+        dbl_to(r, a);
+        return r;
+    }
 
     // canonical packed image XYZZ<Packed> (what the host combine reads)
     MSM_HD void to_packed(uint32_t* w) const {
