@@ -124,12 +124,20 @@ struct XYZZ {
     }
 
     // out-of-line forms for kernels that chain many full additions (bucket reduction)
-    __device__ __noinline__ static XYZZ add_ni(XYZZ a, XYZZ b) { return add(a, b); }
-    __device__ __noinline__ static XYZZ dbl_ni(XYZZ a) { return dbl(a); }
-    // the same through references (operands stay in the caller's frame; two 384-byte by-value arguments of the BLS12-381 G2
-    // point were seen to arrive corrupted in the FFT kernels)
+    // operands by reference: they stay in the caller's frame (two 384-byte by-value arguments of the BLS12-381 G2 point were seen
+    // to arrive corrupted in the FFT kernels)
     __device__ __noinline__ static void add_to(XYZZ& r, const XYZZ& a, const XYZZ& b) { r = add(a, b); }
     __device__ __noinline__ static void dbl_to(XYZZ& r, const XYZZ& a) { r = dbl(a); }
+    MSM_D static XYZZ add_ni(const XYZZ& a, const XYZZ& b) {
+        XYZZ r;
+        add_to(r, a, b);
+        return r;
+    }
+    MSM_D static XYZZ dbl_ni(const XYZZ& a) {
+        XYZZ r;
+        dbl_to(r, a);
+        return r;
+    }
 
     // canonical representation of every coordinate (device values are relaxed, see field.hpp)
     MSM_HD static XYZZ canon(const XYZZ& p) { return {F::canon(p.x), F::canon(p.y), F::canon(p.zz), F::canon(p.zzz)}; }
