@@ -27,8 +27,9 @@
  * buffer; nothing is retained after return.  The reference functions return void and trap on
  * bad memory; these return 0 on success or a negative MSM_AMD_E* code (msm_amd_last_error()
  * gives the text).  n == 0 yields infinity, as build_multiexp.js:283-287 / :119-125.
- * One context serialises its calls (the reference instance is single-threaded too); use one
- * context per thread / per GPU.
+ * A context may be shared by threads: the multiexp entry points serialise submission and collection inside the context and
+ * overlap the GPU work of concurrent callers (up to `slots` calls at a time; further callers wait).  One context per GPU.
+ * msm_amd_set_option and msm_amd_last_error are per context, not per thread.
  */
 #ifndef MSM_AMD_H
 #define MSM_AMD_H

@@ -398,6 +398,37 @@ def test_glv_path_matches_oracle_and_plain_path(eng, orc):
         eng.set_option("glv", 1)
 
 
+def test_concurrent_calls_from_threads(eng, orc):
+    """Several threads issue synchronous calls on ONE context (what the libuv workers behind unresolved JS promises do): the
+    context serialises submission and collection, overlaps the GPU work, and every caller gets its own result."""
+    import threading
+    curve, group, n = "bls12381", 1, 3000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, _ = gu.random_case(curve, group, "gpu:threads", n)
+    jobs = []
+    for t in range(6):
+        _, sc = gu.random_case(curve, group, f"gpu:threads:{t}", n)
+        jobs.append((sc, O.normalize(O.multiexp_affine(bases, sc, 32, n))))
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(4):
+                sc, exp = jobs[(k + rep) % len(jobs)]
+                if C.g1m_multiexpAffine(bases, sc, 32, n) != exp:
+                    errors.append((k, rep))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+
+
 def test_resident_bases_host_scalars(eng, orc):
     """MSM_AMD_DEVICE_BASES: the bases stay on the GPU across calls (a prover's fixed SRS), scalars come from the host."""
     curve, group, n = "bn128", 1, 3000

@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1083,6 +1085,7 @@ struct Slot {
     hipEvent_t ev_c = nullptr;        // second group's reduction done
     std::vector<uint32_t> part_off, part_cnt;   // per owned window: first partial, number of partials
     bool pending = false;
+    bool collecting = false;      // a thread is waiting for / combining this call
     bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
     uint64_t ticket = 0;
     Geom g{};
@@ -1095,6 +1098,12 @@ struct Slot {
 
 struct msm_amd_ctx {
     int device = 0;
+    // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are
+    // serialised by `mu`; WAITING for the GPU happens outside it, so calls issued from different threads -- e.g. the libuv
+    // workers behind two unresolved JS promises -- overlap on the GPU like explicitly pipelined ones.  A synchronous call that
+    // finds every slot taken sleeps on `cv` until one is collected.
+    std::mutex mu;
+    std::condition_variable cv;
     hipStream_t stream = nullptr;     // A: bucket accumulation (the ALU-bound stage), in call order
     hipStream_t stream_s = nullptr;   // S: transfers + bucket sort of the NEXT call, under the current call's accumulation
     static constexpr uint32_t MAX_SLOTS = 8;
@@ -1578,16 +1587,21 @@ static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
 }
 
 // Queue one MSM on the next slot; the caller collects it with finish_ticket().
-static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint64_t* ticket) {
+static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint64_t* ticket, bool wait_for_slot = false) {
     if (!ctx) return MSM_AMD_EINVAL;
+    std::unique_lock<std::mutex> lk(ctx->mu);
     if (int rc = check_args(ctx, a)) return rc;
     Slot* sl = nullptr;
-    for (uint32_t k = 0; k < ctx->nslots; ++k) {   // tickets may be collected in any order: take any free slot
-        Slot* cand = &ctx->slots[(ctx->next_slot + k) % ctx->nslots];
-        if (!cand->pending) {
-            sl = cand;
-            break;
+    for (;;) {
+        for (uint32_t k = 0; k < ctx->nslots; ++k) {   // tickets may be collected in any order: take any free slot
+            Slot* cand = &ctx->slots[(ctx->next_slot + k) % ctx->nslots];
+            if (!cand->pending) {
+                sl = cand;
+                break;
+            }
         }
+        if (sl || !wait_for_slot) break;
+        ctx->cv.wait(lk);   // a synchronous call from another thread holds every slot: wait until one is collected
     }
     if (!sl) {
         ctx->err = "every slot of this context holds an uncollected call: wait for an older ticket first";
@@ -1619,15 +1633,34 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
 
 static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
     if (!ctx || !out) return MSM_AMD_EINVAL;
-    for (Slot& sl : ctx->slots) {
-        if (sl.pending && sl.ticket == ticket) {
-            int rc = sl.finish(ctx, &sl, out);
-            sl.pending = false;
-            return rc;
+    Slot* found = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (Slot& sl : ctx->slots)
+            if (sl.pending && !sl.collecting && sl.ticket == ticket) {
+                found = &sl;
+                sl.collecting = true;
+                break;
+            }
+        if (!found) {
+            ctx->err = "unknown or already collected ticket";
+            return MSM_AMD_EINVAL;
         }
     }
-    ctx->err = "unknown or already collected ticket";
-    return MSM_AMD_EINVAL;
+    // wait for the GPU outside the lock (other threads may submit and collect meanwhile)
+    if (!found->trivial) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipEventSynchronize(found->ev[7]);
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        rc = found->finish(ctx, found, out);
+        found->pending = false;
+        found->collecting = false;
+    }
+    ctx->cv.notify_all();
+    return rc;
 }
 
 static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
@@ -1637,7 +1670,7 @@ static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, ui
         return MSM_AMD_EINVAL;
     }
     uint64_t t = 0;
-    if (int rc = submit(ctx, curve, group, a, &t)) return rc;
+    if (int rc = submit(ctx, curve, group, a, &t, true)) return rc;
     return finish_ticket(ctx, t, out);
 }
 

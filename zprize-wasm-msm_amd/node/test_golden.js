@@ -130,6 +130,19 @@ async function main() {
             checked += 2;
         }
     }
+    // several promises in flight on one curve object: the addon's libuv workers call into ONE context concurrently
+    if (!hostOnly) {
+        const G = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_bls12381.json"))).groups.g1;
+        const pool = fs.readFileSync(path.join(GOLD, G.pool_file));
+        const recs = G.msm.filter((r) => r.fn === "multiexpAffine" && r.scalar_size === 32 && ["rand_n64", "rand_n1024", "rand_n4096"].includes(r.id));
+        const Gx = msm.curve("bls12381").G1;
+        const jobs = [];
+        for (let rep = 0; rep < 4; rep++) for (const r of recs) jobs.push(r);
+        const outs = await Promise.all(jobs.map((r) => { const [b, sc] = inputs("bls12381", G, pool, r, 96); return Gx.multiExpAffine(b, sc); }));
+        const zeroHex = Buffer.from(msm.native.combine(0, 1, new Uint8Array(0))).toString("hex");
+        outs.forEach((o, k) => { if (Buffer.from(o).toString("hex") !== canon(jobs[k].out_norm, 48, zeroHex)) throw new Error("concurrent promises: result differs"); });
+        checked += outs.length;
+    }
     // FFTs (tests/golden/golden_fft.json), in place through the export-shaped surface
     if (!hostOnly) {
         const ff = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_fft.json")));
