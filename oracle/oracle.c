@@ -736,6 +736,107 @@ EXPORT int oracle_fr_batch_apply_key(int curve, const u8 *in, u32 n, const u8 *f
     }
     return 0;
 }
+/* ---- compressed point form: build_curve_jacobian_a0.js:1168-1205 (LEMtoC), :1265-1328 (CtoLEM) ------------------------------ */
+/* build_f1m.js:135-156: 0 for zero, -1 if the plain value is >= (q+1)/2, else 1 */
+static int fp_sign(const Fp *F, const u64 *x) {
+    if (int_is_zero(F->n64, x)) return 0;
+    u64 pl[MAXW], half[MAXW];
+    fp_from_mont(F, x, pl);
+    /* (q+1)/2 */
+    { u128 c = 1; for (int i = 0; i < F->n64; i++) { c += F->q[i]; half[i] = (u64)c; c >>= 64; }
+      for (int i = 0; i < F->n64; i++) half[i] = (half[i] >> 1) | (i < F->n64 - 1 ? half[i + 1] << 63 : 0); }
+    return int_gte(F->n64, pl, half) ? -1 : 1;
+}
+/* build_f2m.js:411-430: sign of c1 unless it is zero, then sign of c0 */
+static int f_sign(const Fld *K, const u64 *x) {
+    if (K->deg == 1) return fp_sign(K->fp, x);
+    int s = fp_sign(K->fp, x + K->fp->n64);
+    return s ? s : fp_sign(K->fp, x);
+}
+static void fp_pow_words(const Fp *F, const u64 *base, const u64 *e, u64 *r) {
+    u64 acc[MAXW], b[MAXW];
+    memcpy(acc, F->one, (size_t)F->n64 * 8); memcpy(b, base, (size_t)F->n64 * 8);
+    for (int i = 0; i < F->n64 * 64; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) fp_mul(F, acc, b, acc);
+        fp_mul(F, b, b, b);
+    }
+    memcpy(r, acc, (size_t)F->n64 * 8);
+}
+/* a square root in Fp, q = 3 mod 4 (both base fields): a^((q+1)/4); returns 0 if a is not a square.  The reference's f1m_sqrt is
+ * Tonelli-Shanks (build_f1m.js); whichever root it returns, CtoLEM then fixes the sign, so only "a root" matters. */
+static int fp_sqrt(const Fp *F, const u64 *a, u64 *r) {
+    u64 e[MAXW], t[MAXW];
+    { u128 c = 1; for (int i = 0; i < F->n64; i++) { c += F->q[i]; e[i] = (u64)c; c >>= 64; }
+      for (int k = 0; k < 2; k++) for (int i = 0; i < F->n64; i++) e[i] = (e[i] >> 1) | (i < F->n64 - 1 ? e[i + 1] << 63 : 0); }
+    fp_pow_words(F, a, e, r);
+    fp_mul(F, r, r, t);
+    return int_eq(F->n64, t, a);
+}
+/* a square root in Fp2 = Fp[u]/(u^2+1) (complex method); returns 0 if a is not a square */
+static int f_sqrt(const Fld *K, const u64 *a, u64 *r) {
+    const Fp *F = K->fp; int n = F->n64;
+    if (K->deg == 1) return fp_sqrt(F, a, r);
+    const u64 *a0 = a, *a1 = a + n;
+    u64 t0[MAXW], t1[MAXW], alpha[MAXW], delta[MAXW], x0[MAXW], x1[MAXW], two[MAXW], inv[MAXW], chk[MAXE];
+    if (int_is_zero(n, a1)) {
+        if (fp_sqrt(F, a0, r)) { memset(r + n, 0, (size_t)n * 8); return 1; }
+        fp_neg(F, a0, t0);
+        if (!fp_sqrt(F, t0, r + n)) return 0;
+        memset(r, 0, (size_t)n * 8); return 1;
+    }
+    fp_mul(F, a0, a0, t0); fp_mul(F, a1, a1, t1); fp_add(F, t0, t1, t0);
+    if (!fp_sqrt(F, t0, alpha)) return 0;
+    fp_add(F, F->one, F->one, two); fp_inverse(F, two, inv);
+    fp_add(F, a0, alpha, delta); fp_mul(F, delta, inv, delta);
+    if (!fp_sqrt(F, delta, x0)) {
+        fp_sub(F, a0, alpha, delta); fp_mul(F, delta, inv, delta);
+        if (!fp_sqrt(F, delta, x0)) return 0;
+    }
+    fp_add(F, x0, x0, t0); fp_inverse(F, t0, t1); fp_mul(F, a1, t1, x1);
+    memcpy(r, x0, (size_t)n * 8); memcpy(r + n, x1, (size_t)n * 8);
+    f_mul(K, r, r, chk);
+    return f_eq(K, chk, a);
+}
+static void reverse_bytes(const u8 *in, size_t n, u8 *out);
+/* LEMtoC with the intended reading of infinity (affine x = y = 0): x big-endian plain, 0x80 on the first byte if sign(y) == -1,
+ * infinity = 0x40 00 .. 00.  (The reference tests infinity with the Jacobian _isZero, which looks past the affine input.) */
+EXPORT int oracle_g_batch_lem_to_c(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    size_t fsz = (size_t)K.nw * 8, n8 = (size_t)K.fp->n64 * 8;
+    for (u32 i = 0; i < n; i++) {
+        u64 a[2 * MAXE]; u8 pl[MAXE * 8];
+        memcpy(a, in + (size_t)i * 2 * fsz, 2 * fsz);
+        u8 *o = out + (size_t)i * fsz;
+        if (g_is_zero_affine(&K, a)) { memset(o, 0, fsz); o[0] = 0x40; continue; }
+        for (int c = 0; c < K.deg; c++) { u64 t[MAXW]; fp_from_mont(K.fp, a + c * K.fp->n64, t); memcpy(pl + c * n8, t, n8); }
+        reverse_bytes(pl, fsz, o);
+        if (f_sign(&K, a + K.nw) == -1) o[0] |= 0x80;
+    }
+    return 0;
+}
+/* CtoLEM: flags from the first byte; y = sqrt(x^3 + b) with the sign the 0x80 flag asks for.  Returns 1 + index of the first x
+ * for which x^3 + b is not a square (the reference's sqrt does not terminate there), 0 on success. */
+EXPORT int oracle_g_batch_c_to_lem(int curve, int group, const u8 *in, u32 n, u8 *out) {
+    Fld K; if (mk(&K, curve, group)) return -1;
+    size_t fsz = (size_t)K.nw * 8, n8 = (size_t)K.fp->n64 * 8;
+    u64 b[MAXE]; curve_b(&K, curve, b);
+    for (u32 i = 0; i < n; i++) {
+        const u8 *p = in + (size_t)i * fsz; u8 *o = out + (size_t)i * 2 * fsz;
+        if (p[0] & 0x40) { memset(o, 0, 2 * fsz); continue; }
+        int greatest = p[0] & 0x80;
+        u8 tmp[MAXE * 8], pl[MAXE * 8];
+        memcpy(tmp, p, fsz); tmp[0] &= 0x3f;
+        reverse_bytes(tmp, fsz, pl);
+        u64 x[MAXE], y[MAXE], t[MAXE];
+        for (int c = 0; c < K.deg; c++) { u64 w[MAXW]; memcpy(w, pl + c * n8, n8); fp_to_mont(K.fp, w, x + c * K.fp->n64); }
+        f_square(&K, x, t); f_mul(&K, x, t, t); f_add(&K, t, b, t);
+        if (!f_sqrt(&K, t, y)) return (int)i + 1;
+        int s = f_sign(&K, y);
+        if ((s == -1) != (greatest != 0)) f_neg(&K, y, y);
+        memcpy(o, x, fsz); memcpy(o + fsz, y, fsz);
+    }
+    return 0;
+}
 /* build_fft.js:23-68: roots of unity of Fr.  maxBits = 2-adicity of r-1, nr = smallest quadratic non-residue >= 2,
  * w[maxBits] = nr^((r-1)/2^maxBits), w[s] = w[s+1]^2; INV2[b] = 2^-b.  All kept in Montgomery form. */
 static void fr_pow(const Fp *R, const u64 *base, const u64 *e, int ewords, u64 *r) {

@@ -125,6 +125,16 @@ class Oracle:
     def batch_lem_to_u(self, aff): return self._batch("oracle_g_batch_lem_to_u", aff, self.asz, self.asz)
     def batch_u_to_lem(self, u): return self._batch("oracle_g_batch_u_to_lem", u, self.asz, self.asz)
 
+    def batch_lem_to_c(self, aff): return self._batch("oracle_g_batch_lem_to_c", aff, self.asz, self.fsz)
+
+    def batch_c_to_lem(self, comp):
+        n = len(comp) // self.fsz
+        out = _buf(max(1, n) * self.asz)
+        rc = self.L.oracle_g_batch_c_to_lem(self.cid, self.group, bytes(comp), n, out)
+        if rc != 0:
+            raise ValueError(f"element {rc - 1}: x^3 + b is not a square")
+        return out.raw[:n * self.asz]
+
     def batch_in_curve_affine(self, aff):
         n = len(aff) // self.asz
         out = _buf(max(1, n))
