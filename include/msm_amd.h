@@ -143,6 +143,12 @@ int msm_amd_batch_to_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t fla
 int msm_amd_batch_to_jacobian(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *jac_out);
 int msm_amd_batch_lem_to_u(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *u_out);
 int msm_amd_batch_u_to_lem(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *u_in, uint32_t n, void *aff_out);
+/* g?m_batchLEMtoC / g?m_batchCtoLEM (build_curve_jacobian_a0.js:1168-1205, 1265-1328, 1414-1416): n affine points <-> n compressed
+ * points of one field element each (x big-endian plain; first byte: 0x80 = y is the "negative" root, 0x40 = infinity).  Infinity is
+ * the affine (0, 0): the reference's LEMtoC tests it with the Jacobian _isZero, i.e. looks past its affine input.  CtoLEM returns
+ * MSM_AMD_EINVAL (and writes infinity) where x^3 + b is not a square; the reference does not terminate on such input.          */
+int msm_amd_batch_lem_to_c(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *aff_in, uint32_t n, void *c_out);
+int msm_amd_batch_c_to_lem(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *c_in, uint32_t n, void *aff_out);
 /* g?m_inCurveAffine (:1330-1353) over a batch: out_flags[i] = 1 iff y^2 == x^3 + b for affine point i ((0,0) gives 0, as
  * in the reference).  out_flags is a host buffer of n bytes unless MSM_AMD_DEVICE_PTRS is set.                           */
 int msm_amd_batch_in_curve_affine(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *points, uint32_t n,

@@ -354,6 +354,39 @@ def test_fft_matches_reference(eng, orc):
         eng.curve("bls12381").frm_fft(bytes(32 * 3))                         # not a power of two
 
 
+def test_compressed_form_matches_reference(eng, orc):
+    """g?m_batchLEMtoC / g?m_batchCtoLEM on the GPU == the reference WASM (golden_compressed.json) and the oracle on a larger batch;
+    an x whose x^3 + b is not a square is reported, not looped on."""
+    import json
+    import os
+    with open(os.path.join(gu.GOLDEN, "golden_compressed.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        C = eng.curve(c["curve"])
+        O = orc.Oracle(c["curve"], c["group"])
+        g = c["group"]
+        aff, comp = bytes.fromhex(c["affine_in"]), bytes.fromhex(c["compressed"])
+        to_c = getattr(C, f"g{g}m_batchLEMtoC")
+        to_lem = getattr(C, f"g{g}m_batchCtoLEM")
+        assert to_c(aff) == comp
+        assert to_lem(comp) == aff
+        big = gu.pool_points(c["curve"], g, list(range(200)))
+        assert to_c(big) == O.batch_lem_to_c(big)
+        assert to_lem(to_c(big)) == big
+    C = eng.curve("bls12381")
+    bad = None
+    for x in range(1, 40):                                    # find an x with x^3 + 4 a non-residue
+        comp = x.to_bytes(48, "big")
+        try:
+            orc.Oracle("bls12381", 1).batch_c_to_lem(comp)
+        except ValueError:
+            bad = comp
+            break
+    assert bad is not None
+    with pytest.raises(Exception):
+        C.g1m_batchCtoLEM(bad)
+
+
 def test_in_group_affine_matches_reference(eng, orc):
     """Batched subgroup check on the GPU == the reference's g?m_inGroupAffine flags (golden_ingroup.json) and the oracle's."""
     import json

@@ -683,6 +683,141 @@ __global__ void __launch_bounds__(256) k_batch_in_curve_affine(const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------
+// Compressed point form: g?m_LEMtoC / g?m_CtoLEM, build_curve_jacobian_a0.js:1168-1205, :1265-1328;
+// sign convention build_f1m.js:135-156 (plain value >= (q+1)/2 is "negative"), build_f2m.js:411-430 (c1 first, then c0).
+// LEMtoC: x big-endian plain, 0x80 on the first byte if sign(y) == -1; infinity (x = y = 0) = 0x40 00 .. 00 -- the reference
+// tests infinity with the Jacobian _isZero, i.e. it looks past its affine input; this is the intended reading.
+// CtoLEM: y = sqrt(x^3 + b) with the sign the 0x80 flag asks for.  Both base fields have q = 3 mod 4: sqrt = a^((q+1)/4);
+// in Fp2 = Fp[u]/(u^2+1) the complex method.  Whichever root the reference's Tonelli-Shanks returns, the sign fix makes y unique.
+// ------------------------------------------------------------------------------------------
+template <class B>
+MSM_D B fp_pow_limbs(const B& base, const uint32_t* e) {
+    B acc = B::one(), b = base;
+    for (int i = 0; i < 32 * B::N; ++i) {
+        if ((e[i >> 5] >> (i & 31)) & 1u) acc = B::mul(acc, b);
+        b = B::sqr(b);
+    }
+    return acc;
+}
+template <class B>
+MSM_D int fp_sign_of(const B& x) {
+    using P = typename B::Params;
+    if (x.is_zero()) return 0;
+    B pl = B::canon(B::from_mont(x));
+    for (int i = B::N - 1; i >= 0; --i) {
+        if (pl.v[i] > P::QP1D2[i]) return -1;
+        if (pl.v[i] < P::QP1D2[i]) return 1;
+    }
+    return -1;
+}
+template <class B>
+MSM_D bool fp_sqrt_of(const B& a, B& r) {
+    using P = typename B::Params;
+    r = fp_pow_limbs<B>(a, P::QP1D4);
+    return B::eq(B::sqr(r), a);
+}
+template <class F>
+struct CompOps;
+template <class P>
+struct CompOps<Fp<P>> {
+    using F = Fp<P>;
+    MSM_D static int sign(const F& x) { return fp_sign_of<F>(x); }
+    MSM_D static bool sqrt(const F& a, F& r) { return fp_sqrt_of<F>(a, r); }
+};
+template <class P>
+struct CompOps<Fp2<P>> {
+    using F = Fp2<P>;
+    using B = Fp<P>;
+    MSM_D static int sign(const F& x) {
+        int s = fp_sign_of<B>(x.c1);
+        return s ? s : fp_sign_of<B>(x.c0);
+    }
+    MSM_D static bool sqrt(const F& a, F& r) {
+        if (a.c1.is_zero()) {
+            if (fp_sqrt_of<B>(a.c0, r.c0)) {
+                r.c1 = B::zero();
+                return true;
+            }
+            r.c0 = B::zero();
+            return fp_sqrt_of<B>(B::neg(a.c0), r.c1);
+        }
+        B alpha;
+        if (!fp_sqrt_of<B>(B::add(B::sqr(a.c0), B::sqr(a.c1)), alpha)) return false;
+        const B inv2 = B::inv(B::add(B::one(), B::one()));
+        B x0;
+        if (!fp_sqrt_of<B>(B::mul(B::add(a.c0, alpha), inv2), x0))
+            if (!fp_sqrt_of<B>(B::mul(B::sub(a.c0, alpha), inv2), x0)) return false;
+        r.c0 = x0;
+        r.c1 = B::mul(a.c1, B::inv(B::add(x0, x0)));
+        return F::eq(F::sqr(r), a);
+    }
+};
+template <class F, class B>
+__global__ void __launch_bounds__(256) k_batch_lem_to_c(const uint8_t* __restrict__ aff, uint32_t n, uint8_t* __restrict__ out) {
+    constexpr int T = sizeof(F) / 4, NB = sizeof(B) / 4, COMP = T / NB;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine<F> p = load16<Affine<F>>(aff + (size_t)i * sizeof(Affine<F>));
+    F o;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+    if (p.is_inf()) {
+#pragma unroll
+        for (int k = 0; k < T; ++k) ow[k] = 0;
+        ow[0] = 0x40u;
+    } else {
+        uint32_t plain[T];
+        const B* comps = reinterpret_cast<const B*>(&p.x);
+#pragma unroll
+        for (int k = 0; k < COMP; ++k) {
+            B v = B::canon(B::from_mont(comps[k]));
+#pragma unroll
+            for (int l = 0; l < NB; ++l) plain[k * NB + l] = v.v[l];
+        }
+#pragma unroll
+        for (int l = 0; l < T; ++l) ow[l] = bswap32(plain[T - 1 - l]);
+        if (CompOps<F>::sign(p.y) == -1) ow[0] |= 0x80u;
+    }
+    store16(out + (size_t)i * sizeof(F), o);
+}
+template <class F, class B>
+__global__ void __launch_bounds__(256) k_batch_c_to_lem(const uint8_t* __restrict__ in, uint32_t n, F b, uint8_t* __restrict__ aff, uint32_t* __restrict__ bad) {
+    constexpr int T = sizeof(F) / 4, NB = sizeof(B) / 4, COMP = T / NB;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    F u = load16<F>(in + (size_t)i * sizeof(F));
+    uint32_t* uw = reinterpret_cast<uint32_t*>(&u);
+    Affine<F> o;
+    uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+    if (uw[0] & 0x40u) {
+#pragma unroll
+        for (int k = 0; k < 2 * T; ++k) ow[k] = 0;
+    } else {
+        const bool greatest = (uw[0] & 0x80u) != 0;
+        uw[0] &= ~0xC0u;
+        uint32_t plain[T];
+#pragma unroll
+        for (int l = 0; l < T; ++l) plain[l] = bswap32(uw[T - 1 - l]);
+        B* xc = reinterpret_cast<B*>(&o.x);
+#pragma unroll
+        for (int k = 0; k < COMP; ++k) {
+            B v;
+#pragma unroll
+            for (int l = 0; l < NB; ++l) v.v[l] = plain[k * NB + l];
+            xc[k] = B::canon(B::to_mont(v));
+        }
+        F y;
+        if (!CompOps<F>::sqrt(F::add(F::mul(o.x, F::sqr(o.x)), b), y)) {
+            atomicAdd(bad, 1u);
+            y = F::zero();
+        }
+        y = F::canon(y);
+        if ((CompOps<F>::sign(y) == -1) != greatest) y = F::canon(F::neg(y));
+        o.y = y;
+    }
+    store16(aff + (size_t)i * sizeof(Affine<F>), o);
+}
+
+// ------------------------------------------------------------------------------------------
 // batchApplyKey (build_applykey.js:20-76 wired at bls12381/build_bls12381.js:79-92, bn128/build_bn128.js:84-88):
 //   out[i] = (first * inc^i) * in[i],  first / inc in Fr, Montgomery form.
 // The reference walks i sequentially (t = t * inc); here lane i raises inc to the i-th power itself (<= 2 * 27 Montgomery
@@ -1682,12 +1817,6 @@ static int gen_points_t(msm_amd_ctx* ctx, const Affine<F>& gen, uint64_t seed, u
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
-template <class P>
-static Fp<P> fp_from(const uint32_t* limbs) {
-    Fp<P> r;
-    for (int i = 0; i < P::N; ++i) r.v[i] = limbs[i];
-    return r;
-}
 
 template <class F>
 static int combine_t(const uint8_t* partials, uint32_t count, uint8_t* out) {
@@ -1710,9 +1839,9 @@ static int f_conv(const uint8_t* in, uint32_t count, uint8_t* out) {
 
 // ---- batch conversions (g?m_batchToAffine / _batchToJacobian / _batchLEMtoU / _batchUtoLEM) ----------------
 template <class F, class B>
-static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, uint32_t n, void* out) {
-    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
-    const size_t in_b = (size_t)n * (which == 0 ? JSZ : ASZ), out_b = (size_t)n * (which == 1 ? JSZ : ASZ);
+static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, uint32_t n, void* out, const F* curve_b = nullptr) {
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), FSZ = sizeof(F);
+    const size_t in_b = (size_t)n * (which == 0 ? JSZ : which == 5 ? FSZ : ASZ), out_b = (size_t)n * (which == 1 ? JSZ : which == 4 ? FSZ : ASZ);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
@@ -1735,10 +1864,21 @@ static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, u
     if (which == 0) k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
     else if (which == 1) k_batch_to_jacobian<F><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
     else if (which == 2) k_batch_lem_to_u<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
-    else k_batch_u_to_lem<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    else if (which == 3) k_batch_u_to_lem<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    else if (which == 4) k_batch_lem_to_c<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    uint32_t* dbad = nullptr;
+    uint32_t hbad = 0;
+    if (which == 5) {
+        if (hipMalloc(&dbad, 4) == hipSuccess) {
+            (void)hipMemsetAsync(dbad, 0, 4, st);
+            k_batch_c_to_lem<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, *curve_b, (uint8_t*)dout, dbad);
+            (void)hipMemcpyAsync(&hbad, dbad, 4, hipMemcpyDeviceToHost, st);
+        }
+    }
     hipError_t e = hipGetLastError();
     if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, out_b, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (dbad) (void)hipFree(dbad);
     if (!dev) {
         (void)hipFree(di);
         (void)hipFree(dout);
@@ -1747,7 +1887,17 @@ static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, u
         ctx->err = std::string("batch conversion: ") + hipGetErrorString(e);
         return MSM_AMD_EHIP;
     }
+    if (hbad) {
+        ctx->err = "CtoLEM: x^3 + b is not a square for " + std::to_string(hbad) + " element(s) (written as infinity; the reference does not terminate on such input)";
+        return MSM_AMD_EINVAL;
+    }
     return 0;
+}
+template <class P>
+static Fp<P> fp_from(const uint32_t* limbs) {
+    Fp<P> r;
+    for (int i = 0; i < P::N; ++i) r.v[i] = limbs[i];
+    return r;
 }
 static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flags, const void* in, uint32_t n, void* out) {
     if (!ctx) return MSM_AMD_EINVAL;
@@ -1756,10 +1906,26 @@ static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flag
         ctx->err = "null pointer";
         return MSM_AMD_EINVAL;
     }
-    if (curve == MSM_AMD_BLS12381 && group == 1) return conv_t<Fp<Bls12381Fp>, Fp<Bls12381Fp>>(ctx, which, flags, in, n, out);
-    if (curve == MSM_AMD_BLS12381 && group == 2) return conv_t<Fp2<Bls12381Fp>, Fp<Bls12381Fp>>(ctx, which, flags, in, n, out);
-    if (curve == MSM_AMD_BN128 && group == 1) return conv_t<Fp<Bn254Fp>, Fp<Bn254Fp>>(ctx, which, flags, in, n, out);
-    if (curve == MSM_AMD_BN128 && group == 2) return conv_t<Fp2<Bn254Fp>, Fp<Bn254Fp>>(ctx, which, flags, in, n, out);
+    if (curve == MSM_AMD_BLS12381 && group == 1) {
+        using P = Bls12381Fp;
+        const Fp<P> b = fp_from<P>(P::B1);
+        return conv_t<Fp<P>, Fp<P>>(ctx, which, flags, in, n, out, &b);
+    }
+    if (curve == MSM_AMD_BLS12381 && group == 2) {
+        using P = Bls12381Fp;
+        const Fp2<P> b{fp_from<P>(P::B2_0), fp_from<P>(P::B2_1)};
+        return conv_t<Fp2<P>, Fp<P>>(ctx, which, flags, in, n, out, &b);
+    }
+    if (curve == MSM_AMD_BN128 && group == 1) {
+        using P = Bn254Fp;
+        const Fp<P> b = fp_from<P>(P::B1);
+        return conv_t<Fp<P>, Fp<P>>(ctx, which, flags, in, n, out, &b);
+    }
+    if (curve == MSM_AMD_BN128 && group == 2) {
+        using P = Bn254Fp;
+        const Fp2<P> b{fp_from<P>(P::B2_0), fp_from<P>(P::B2_1)};
+        return conv_t<Fp2<P>, Fp<P>>(ctx, which, flags, in, n, out, &b);
+    }
     ctx->err = "unknown curve/group";
     return MSM_AMD_EINVAL;
 }
@@ -2126,6 +2292,12 @@ int msm_amd_batch_lem_to_u(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
 }
 int msm_amd_batch_u_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* u_in, uint32_t n, void* aff_out) {
     return conv(ctx, 3, curve, group, flags, u_in, n, aff_out);
+}
+int msm_amd_batch_lem_to_c(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* aff_in, uint32_t n, void* c_out) {
+    return conv(ctx, 4, curve, group, flags, aff_in, n, c_out);
+}
+int msm_amd_batch_c_to_lem(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* c_in, uint32_t n, void* aff_out) {
+    return conv(ctx, 5, curve, group, flags, c_in, n, aff_out);
 }
 
 int msm_amd_fft(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* in, uint32_t n, void* out) {

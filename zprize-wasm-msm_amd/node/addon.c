@@ -43,7 +43,7 @@ static int (*p_fft)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, v
 static int (*p_apply_key)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
 static int (*p_fr_apply_key)(msm_amd_ctx *, int, uint32_t, const void *, uint32_t, const uint8_t *, const uint8_t *, void *);
 static int (*p_check[2])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint8_t *);
-static int (*p_conv[4])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
+static int (*p_conv[6])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, void *);
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
 static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
@@ -86,6 +86,8 @@ static const char *load_engine(void) {
     SYM(p_fr_apply_key, "msm_amd_fr_batch_apply_key")
     SYM(p_check[0], "msm_amd_batch_in_curve_affine")
     SYM(p_check[1], "msm_amd_batch_in_group_affine")
+    SYM(p_conv[4], "msm_amd_batch_lem_to_c")
+    SYM(p_conv[5], "msm_amd_batch_c_to_lem")
     SYM(p_conv[0], "msm_amd_batch_to_affine")
     SYM(p_conv[1], "msm_amd_batch_to_jacobian")
     SYM(p_conv[2], "msm_amd_batch_lem_to_u")
@@ -484,13 +486,13 @@ static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
     const uint8_t *in;
     size_t lin;
     if (argc < 5 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &which) || get_i32(env, argv[2], &curve) ||
-        get_i32(env, argv[3], &group) || get_bytes(env, argv[4], &in, &lin) || which < 0 || which > 3 || (curve != 0 && curve != 1) ||
+        get_i32(env, argv[3], &group) || get_bytes(env, argv[4], &in, &lin) || which < 0 || which > 5 || (curve != 0 && curve != 1) ||
         (group != 1 && group != 2)) {
-        napi_throw_type_error(env, NULL, "batchConvert(ctx, which 0..3, curve, group, Uint8Array)");
+        napi_throw_type_error(env, NULL, "batchConvert(ctx, which 0..5, curve, group, Uint8Array)");
         return NULL;
     }
     size_t fsz = (size_t)n8_of(curve) * group;
-    size_t in_sz = (which == 0 ? 3 : 2) * fsz, out_sz = (which == 1 ? 3 : 2) * fsz;
+    size_t in_sz = (which == 0 ? 3 : which == 5 ? 1 : 2) * fsz, out_sz = (which == 1 ? 3 : which == 4 ? 1 : 2) * fsz;   /* 4: LEMtoC, 5: CtoLEM */
     if (lin % in_sz) {
         napi_throw_range_error(env, NULL, "input is not a whole number of points");
         return NULL;

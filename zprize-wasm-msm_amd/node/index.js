@@ -91,6 +91,8 @@ function instantiate(curveName, imports, opts) {
         ex[`${pf}_batchToJacobian`] = conv(1, 2 * fsz, 3 * fsz);
         ex[`${pf}_batchLEMtoU`] = conv(2, 2 * fsz, 2 * fsz);
         ex[`${pf}_batchUtoLEM`] = conv(3, 2 * fsz, 2 * fsz);
+        ex[`${pf}_batchLEMtoC`] = conv(4, 2 * fsz, fsz);
+        ex[`${pf}_batchCtoLEM`] = conv(5, fsz, 2 * fsz);
         // comparison helpers the reference's tests use around the MSM
         ex[`${pf}_normalize`] = (p, pr) => u8().set(native.normalize(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);
         ex[`${pf}_toAffine`] = (p, pr) => u8().set(native.toAffine(C.id, g, u8().subarray(p, p + 3 * fsz)), pr);
@@ -147,6 +149,8 @@ function curve(curveName, opts) {
             batchToJacobian: async (buff) => native.batchConvert(ctx, 1, C.id, g, buff),
             batchLEMtoU: async (buff) => native.batchConvert(ctx, 2, C.id, g, buff),
             batchUtoLEM: async (buff) => native.batchConvert(ctx, 3, C.id, g, buff),
+            batchLEMtoC: async (buff) => native.batchConvert(ctx, 4, C.id, g, buff),
+            batchCtoLEM: async (buff) => native.batchConvert(ctx, 5, C.id, g, buff),
             normalize: (p) => native.normalize(C.id, g, p),
             toAffine: (p) => native.toAffine(C.id, g, p),
             eq: (a, b) => native.eq(C.id, g, a, b),

@@ -130,6 +130,21 @@ async function main() {
             checked += 2;
         }
     }
+    // compressed point form (tests/golden/golden_compressed.json)
+    if (!hostOnly) {
+        const cc = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_compressed.json")));
+        for (const c of cc.cases) {
+            const memory = new WebAssembly.Memory({ initial: 8 });
+            const m = msm.instantiate(c.curve, { memory });
+            const aff = Buffer.from(c.affine_in, "hex"), pA = 1024, pC = pA + aff.length, pB = pC + aff.length, pf = `g${c.group}m`;
+            new Uint8Array(memory.buffer).set(aff, pA);
+            m[`${pf}_batchLEMtoC`](pA, c.n, pC);
+            if (Buffer.from(new Uint8Array(memory.buffer).slice(pC, pC + aff.length / 2)).toString("hex") !== c.compressed) throw new Error("batchLEMtoC differs");
+            m[`${pf}_batchCtoLEM`](pC, c.n, pB);
+            if (Buffer.from(new Uint8Array(memory.buffer).slice(pB, pB + aff.length)).toString("hex") !== c.affine_in) throw new Error("batchCtoLEM differs");
+            checked += 2;
+        }
+    }
     // several promises in flight on one curve object: the addon's libuv workers call into ONE context concurrently
     if (!hostOnly) {
         const G = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_bls12381.json"))).groups.g1;

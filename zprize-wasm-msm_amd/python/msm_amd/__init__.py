@@ -69,6 +69,8 @@ def load_library(path=None):
     L.msm_amd_f_from_montgomery.argtypes = [c.c_int, vp, u32, u8p]
     for _fn in ("msm_amd_batch_to_affine", "msm_amd_batch_to_jacobian", "msm_amd_batch_lem_to_u", "msm_amd_batch_u_to_lem"):
         getattr(L, _fn).argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_batch_lem_to_c.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_batch_c_to_lem.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_curve_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_in_group_affine.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
     L.msm_amd_batch_apply_key.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp, vp, vp]
@@ -300,6 +302,11 @@ class Curve:
     def g2m_batchLEMtoU(self, aff): return self._conv("msm_amd_batch_lem_to_u", 2, aff, self.affine_bytes(2), self.affine_bytes(2))
     def g1m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 1, u, self.affine_bytes(1), self.affine_bytes(1))
     def g2m_batchUtoLEM(self, u): return self._conv("msm_amd_batch_u_to_lem", 2, u, self.affine_bytes(2), self.affine_bytes(2))
+
+    def g1m_batchLEMtoC(self, aff): return self._conv("msm_amd_batch_lem_to_c", 1, aff, self.affine_bytes(1), self.field_bytes(1))
+    def g2m_batchLEMtoC(self, aff): return self._conv("msm_amd_batch_lem_to_c", 2, aff, self.affine_bytes(2), self.field_bytes(2))
+    def g1m_batchCtoLEM(self, comp): return self._conv("msm_amd_batch_c_to_lem", 1, comp, self.field_bytes(1), self.affine_bytes(1))
+    def g2m_batchCtoLEM(self, comp): return self._conv("msm_amd_batch_c_to_lem", 2, comp, self.field_bytes(2), self.affine_bytes(2))
 
     def batch_in_curve_affine(self, group, points):
         """g?m_inCurveAffine over a batch: list of 0/1 flags"""
