@@ -151,12 +151,23 @@ function curve(curveName, opts) {
             batchUtoLEM: async (buff) => native.batchConvert(ctx, 3, C.id, g, buff),
             batchLEMtoC: async (buff) => native.batchConvert(ctx, 4, C.id, g, buff),
             batchCtoLEM: async (buff) => native.batchConvert(ctx, 5, C.id, g, buff),
+            // Jacobian in, normalised Jacobian out (ffjavascript: G.fft / G.ifft / G.batchApplyKey)
+            fft: async (buff) => native.fft(ctx, C.id, g, 0, buff),
+            ifft: async (buff) => native.fft(ctx, C.id, g, 1, buff),
+            batchApplyKey: async (buff, first, inc, inType = "jacobian") => native.batchApplyKey(ctx, C.id, g, inType === "affine" ? 0 : 1, buff, first, inc),
             normalize: (p) => native.normalize(C.id, g, p),
             toAffine: (p) => native.toAffine(C.id, g, p),
             eq: (a, b) => native.eq(C.id, g, a, b),
         };
     };
-    return { name: curveName, n8q: C.n8, n8r: 32, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c) };
+    // scalar field: Montgomery elements of 32 bytes
+    const Fr = {
+        n8: 32,
+        fft: async (buff) => native.fft(ctx, C.id, 0, 0, buff),
+        ifft: async (buff) => native.fft(ctx, C.id, 0, 1, buff),
+        batchApplyKey: async (buff, first, inc) => native.batchApplyKey(ctx, C.id, 0, 0, buff, first, inc),
+    };
+    return { name: curveName, n8q: C.n8, n8r: 32, Fr, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c) };
 }
 
 module.exports = { instantiate, curve, native, CURVES };

@@ -182,6 +182,11 @@ async function main() {
                 if (got !== exp) throw new Error(`${pf}_${fn} differs (${c.curve} n=${c.n})`);
             }
             checked += 2;
+            if (c.group === 0 && c.n === 256) {   // the buffer-shaped surface
+                const Fr = msm.curve(c.curve).Fr;
+                if (Buffer.from(await Fr.fft(inp)).toString("hex") !== c.fft || Buffer.from(await Fr.ifft(inp)).toString("hex") !== c.ifft) throw new Error("Fr.fft (buffer surface) differs");
+                checked++;
+            }
         }
     }
     // batchApplyKey (tests/golden/golden_applykey.json) through the export-shaped surface
