@@ -14,6 +14,8 @@
 // and canon() restores the reference's [0, q) representation wherever a value leaves the engine.
 // The HOST build of the same templates stays canonical throughout.
 //
+// This packed field serves the engine's auxiliary kernels (conversions, checks, generated points, FFTs) and, in its
+// 64-bit twin field_host.hpp, the host combine; the ALU-bound bucket kernels use the unsaturated form of field_u.hpp.
 // Device multiplier: product-scanning Montgomery on 32-bit limbs.  v_mad_u64_u32 issues at full
 // rate on gfx950 (profiles/r01_valu_rates_microbench.txt), so one instruction does a 32x32
 // multiply and a 64-bit accumulate; its carry-out is folded into a third accumulator word with
@@ -56,8 +58,9 @@ MSM_HD void mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 #endif
 }
 
-// INL = true: multiplies are expanded inline at every use (the G1 bucket kernels: no call overhead,
-// no spills around calls); INL = false: one out-of-line body per translation unit (small code).
+// INL = true: multiplies are expanded inline at every use; INL = false: one out-of-line body per translation unit
+// (small code) -- what every kernel of msm_engine.hip uses.  The bucket kernels no longer compute in this packed
+// representation at all (field_u.hpp); Fp<P, true> survives as the tag under which their G1 instantiations are named.
 // Both flavours have the same layout and value semantics.
 template <class P, bool INL = false>
 struct Fp {
