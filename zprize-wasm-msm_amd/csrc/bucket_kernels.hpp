@@ -244,7 +244,12 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbet
 #else
     static_assert(VARIANT == 0, "this translation unit builds the two-chain variant");
 #endif
-    k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + 255) / 256), 256, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
+    // one wave per workgroup: a SIMD takes the next wave as soon as one of its own finishes instead of waiting until a whole
+    // CU can host four (measured: 2.29 -> 2.24 ms for the kernel at n = 2^20)
+#ifndef MSM_ACC_BLOCK
+#define MSM_ACC_BLOCK 64
+#endif
+    k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK), MSM_ACC_BLOCK, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
                                                                                 (uint2*)work, (uint4*)biglist);
 }
 template <class F>
