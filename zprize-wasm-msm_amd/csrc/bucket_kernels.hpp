@@ -86,6 +86,15 @@ template <class P>
 struct InlineAdds<Fp<P, true>> {
     static constexpr bool value = true;
 };
+// additions expanded inline in the reduction / tail-combine kernels (G1 always; experiment: G2 too)
+template <class F>
+struct ReduceInline {
+#ifdef MSM_G2_REDUCE_INLINE
+    static constexpr bool value = true;
+#else
+    static constexpr bool value = InlineAdds<F>::value;
+#endif
+};
 // Occupancy target of the accumulation (waves per SIMD): 3 for G1 -- the kernel needs 165 VGPRs, three waves keep the
 // v_mad_u64_u32 pipe fed through the point loads; the Fp2 kernels need all 512 registers of a SIMD lane pair.
 #ifndef MSM_ACC_WAVES
@@ -176,12 +185,12 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
 // ------------------------------------------------------------------------------------------
 template <class F>
 MSM_D BU<F> radd(const BU<F>& a, const BU<F>& b) {
-    if constexpr (InlineAdds<F>::value) return BU<F>::add(a, b);
+    if constexpr (ReduceInline<F>::value) return BU<F>::add(a, b);
     else return BU<F>::add_ni(a, b);
 }
 template <class F>
 MSM_D BU<F> rdbl(const BU<F>& a) {
-    if constexpr (InlineAdds<F>::value) return BU<F>::dbl(a);
+    if constexpr (ReduceInline<F>::value) return BU<F>::dbl(a);
     else return BU<F>::dbl_ni(a);
 }
 
@@ -281,12 +290,14 @@ uint32_t lanes_per_point() {
 #define MSM_INSTANTIATE_ACCUMULATE(F, VARIANT)                                                                                               \
     template void launch_accumulate<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*);
-#define MSM_INSTANTIATE_TAIL_AND_REDUCE(F)                                                                                                   \
+#define MSM_INSTANTIATE_TAIL(F)                                                                                                              \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
-                                            uint32_t, void*, void*, void*, uint8_t*, uint32_t);                                              \
+                                            uint32_t, void*, void*, void*, uint8_t*, uint32_t);
+#define MSM_INSTANTIATE_REDUCE(F)                                                                                                            \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
     template size_t bucket_bytes<F>();                                                                                                        \
     template uint32_t lanes_per_point<F>();
+#define MSM_INSTANTIATE_TAIL_AND_REDUCE(F) MSM_INSTANTIATE_TAIL(F) MSM_INSTANTIATE_REDUCE(F)
 #define MSM_INSTANTIATE_BUCKET_KERNELS(F) MSM_INSTANTIATE_ACCUMULATE(F, 0) MSM_INSTANTIATE_TAIL_AND_REDUCE(F)
 
 }  // namespace msm
