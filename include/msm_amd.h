@@ -18,7 +18,8 @@
  *   affine point  : x || y            ; infinity = all-zero bytes
  *   Jacobian point: X || Y || Z       ; infinity <=> Z == 0
  *   scalars       : n * scalar_size bytes, plain little-endian integers (not Montgomery, not
- *                   reduced mod r; any value < 2^(8*scalar_size)), 1 <= scalar_size <= 64; n <= 2^27 per call
+ *                   reduced mod r; any value < 2^(8*scalar_size)), 1 <= scalar_size <= 64; any n < 2^32 for the
+ *                   synchronous calls (inputs beyond 2^26 points are processed in slices), n <= 2^27 per asynchronous call
  *   output        : one Jacobian point, ALWAYS normalised: (x, y, R) or (0, R, 0) for infinity,
  *                   i.e. byte-equal to g?m_normalize() of the reference's result
  *                   (build_curve_jacobian_a0.js:940-973).

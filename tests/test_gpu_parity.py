@@ -431,6 +431,29 @@ def test_glv_path_matches_oracle_and_plain_path(eng, orc):
         eng.set_option("glv", 1)
 
 
+def test_point_slicing_of_large_synchronous_calls(eng, orc):
+    """More points than one pass takes are cut into slices (two in flight) and the partial results added on the host.  The slice size
+    is lowered with the "slice" option so that the path runs at test sizes: full calls, a _chunk call, Jacobian bases, G2, and a
+    window shard all give the oracle's answer."""
+    import msm_amd
+    try:
+        eng.set_option("slice", 1000)
+        for curve, group, n in (("bls12381", 1, 4500), ("bn128", 2, 2300)):
+            C = eng.curve(curve)
+            O = orc.Oracle(curve, group)
+            bases, scalars = gu.random_case(curve, group, f"gpu:slices:{curve}:{group}", n)
+            bases = bases[:O.asz * 7] + bytes(O.asz) + bases[O.asz * 8:]
+            exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+            assert _fn(C, group, True)(bases, scalars, 32, n) == exp
+            assert _fn(C, group, False)(O.batch_to_jacobian(bases), scalars, 32, n) == exp
+            chunk = O.normalize(O.multiexp_chunk(bases, scalars, 32, n, 37, 11))
+            assert _fn(C, group, True, True)(bases, scalars, 32, n, 37, 11) == chunk
+            parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, r, 3) for r in range(3))
+            assert msm_amd.combine(curve, group, parts) == exp
+    finally:
+        eng.set_option("slice", 1 << 26)
+
+
 def test_concurrent_calls_from_threads(eng, orc):
     """Several threads issue synchronous calls on ONE context (what the libuv workers behind unresolved JS promises do): the
     context serialises submission and collection, overlaps the GPU work, and every caller gets its own result."""

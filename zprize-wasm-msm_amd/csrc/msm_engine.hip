@@ -1250,6 +1250,7 @@ struct msm_amd_ctx {
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
@@ -1711,7 +1712,7 @@ static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
         return MSM_AMD_EINVAL;
     }
     if (a.n > (1u << 27)) {   // (pair, window) positions are 32-bit: 17 windows x n must stay below 2^32
-        ctx->err = "n must not exceed 2^27 per call (split larger inputs by points and add the results with msm_amd_combine)";
+        ctx->err = "n must not exceed 2^27 per asynchronous call (the synchronous entry points slice larger inputs themselves)";
         return MSM_AMD_EINVAL;
     }
     if (a.nshards == 0 || a.shard >= a.nshards) {
@@ -1798,15 +1799,53 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
     return rc;
 }
 
+static size_t elem_bytes(int curve, int group) { return (size_t)(curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group; }
 static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
     if (!ctx) return MSM_AMD_EINVAL;
     if (!out) {
         ctx->err = "null pointer";
         return MSM_AMD_EINVAL;
     }
-    uint64_t t = 0;
-    if (int rc = submit(ctx, curve, group, a, &t, true)) return rc;
-    return finish_ticket(ctx, t, out);
+    if (a.n <= ctx->max_slice) {
+        uint64_t t = 0;
+        if (int rc = submit(ctx, curve, group, a, &t, true)) return rc;
+        return finish_ticket(ctx, t, out);
+    }
+    // More points than one pass takes (the reference's external caller slices at 2^22 for its own reasons): the MSM is linear in the
+    // points, so run slice after slice -- two in flight -- and add the partial results on the host.  Works for host and for device
+    // pointers alike (plain address arithmetic); a shard call stays a shard call per slice.
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || !a.bases || !a.scalars) {
+        ctx->err = "bad argument";
+        return MSM_AMD_EINVAL;
+    }
+    const size_t bstride = ((a.flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * elem_bytes(curve, group), jsz = 3 * elem_bytes(curve, group);
+    std::vector<uint8_t> parts;
+    uint64_t pending_ticket = 0;
+    bool have_pending = false;
+    int rc = 0;
+    for (uint64_t off = 0; off < a.n && rc == 0; off += ctx->max_slice) {
+        RunArgs s = a;
+        s.n = (uint32_t)std::min<uint64_t>(ctx->max_slice, a.n - off);
+        s.bases = (const uint8_t*)a.bases + off * bstride;
+        s.scalars = (const uint8_t*)a.scalars + off * a.scalar_size;
+        s.raw_out = true;   // un-normalised partial: one inversion at the very end
+        uint64_t t = 0;
+        rc = submit(ctx, curve, group, s, &t, true);
+        if (rc) break;
+        if (have_pending) {
+            parts.resize(parts.size() + jsz);
+            rc = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+        }
+        pending_ticket = t;
+        have_pending = true;
+    }
+    if (have_pending) {
+        parts.resize(parts.size() + jsz);
+        int rc2 = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+        if (!rc) rc = rc2;
+    }
+    if (rc) return rc;
+    return msm_amd_combine(curve, group, parts.data(), (uint32_t)(parts.size() / jsz), out);   // normalised (for a shard too: any representative will do)
 }
 
 template <class F>
@@ -2170,6 +2209,11 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
+    if (!strcmp(name, "slice")) {
+        if (value < 1 || value > (1u << 27)) { ctx->err = "slice must be in [1, 2^27]"; return MSM_AMD_EINVAL; }
+        ctx->max_slice = value;
+        return 0;
+    }
     if (!strcmp(name, "slots")) {
         if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { ctx->err = "slots must be in [1, 8]"; return MSM_AMD_EINVAL; }
         for (Slot& sl : ctx->slots)
