@@ -438,6 +438,12 @@ def test_point_slicing_of_large_synchronous_calls(eng, orc):
     import msm_amd
     try:
         eng.set_option("slice", 1000)
+        eng.set_option("slots", 1)                       # a single slot must not wait on itself
+        C = eng.curve("bn128")
+        O = orc.Oracle("bn128", 1)
+        bases, scalars = gu.random_case("bn128", 1, "gpu:slices:oneslot", 3100)
+        assert C.g1m_multiexpAffine(bases, scalars, 32, 3100) == O.normalize(O.multiexp_affine(bases, scalars, 32, 3100))
+        eng.set_option("slots", 2)
         for curve, group, n in (("bls12381", 1, 4500), ("bn128", 2, 2300)):
             C = eng.curve(curve)
             O = orc.Oracle(curve, group)
@@ -451,6 +457,7 @@ def test_point_slicing_of_large_synchronous_calls(eng, orc):
             parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, r, 3) for r in range(3))
             assert msm_amd.combine(curve, group, parts) == exp
     finally:
+        eng.set_option("slots", 2)
         eng.set_option("slice", 1 << 26)
 
 

@@ -1829,6 +1829,12 @@ static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, ui
         s.bases = (const uint8_t*)a.bases + off * bstride;
         s.scalars = (const uint8_t*)a.scalars + off * a.scalar_size;
         s.raw_out = true;   // un-normalised partial: one inversion at the very end
+        if (have_pending && ctx->nslots < 2) {   // a single slot: no overlap between slices (and no waiting on ourselves)
+            parts.resize(parts.size() + jsz);
+            rc = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+            have_pending = false;
+            if (rc) break;
+        }
         uint64_t t = 0;
         rc = submit(ctx, curve, group, s, &t, true);
         if (rc) break;
