@@ -176,6 +176,8 @@ def test_async_pipeline_two_in_flight(eng, orc):
     t1 = eng.curve(cases[1][0]).multiexp_async(cases[1][1], cases[1][3], cases[1][4], 32, cases[1][2])
     with pytest.raises(msm_amd.MsmAmdError):
         eng.curve("bls12381").multiexp_async(1, cases[0][3], cases[0][4], 32, cases[0][2])
+    with pytest.raises(msm_amd.MsmAmdError):      # a synchronous call cannot wait for tickets only its own caller can collect
+        eng.curve("bn128").g1m_multiexpAffine(cases[1][3], cases[1][4], 32, cases[1][2])
     assert t1.wait() == cases[1][5]
     t2 = eng.curve(cases[2][0]).multiexp_async(cases[2][1], cases[2][3], cases[2][4], 32, cases[2][2])
     assert t0.wait() == cases[0][5]

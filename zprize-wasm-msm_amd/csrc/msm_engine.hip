@@ -1221,6 +1221,7 @@ struct Slot {
     std::vector<uint32_t> part_off, part_cnt;   // per owned window: first partial, number of partials
     bool pending = false;
     bool collecting = false;      // a thread is waiting for / combining this call
+    bool sync_owned = false;      // submitted by a synchronous entry point: its own thread will collect it
     bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
     uint64_t ticket = 0;
     Geom g{};
@@ -1737,7 +1738,12 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
             }
         }
         if (sl || !wait_for_slot) break;
-        ctx->cv.wait(lk);   // a synchronous call from another thread holds every slot: wait until one is collected
+        // every slot is taken.  Slots held by synchronous calls of other threads will be collected by those threads: wait for one.
+        // If all of them hold asynchronous tickets, only the caller can free one -- waiting would never end.
+        bool some_sync = false;
+        for (uint32_t k = 0; k < ctx->nslots; ++k) some_sync |= ctx->slots[k].sync_owned;
+        if (!some_sync) break;
+        ctx->cv.wait(lk);
     }
     if (!sl) {
         ctx->err = "every slot of this context holds an uncollected call: wait for an older ticket first";
@@ -1761,6 +1767,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return rc;
     }
     sl->pending = true;
+    sl->sync_owned = wait_for_slot;
     sl->ticket = ctx->next_ticket++;
     *ticket = sl->ticket;
     ctx->next_slot = ((uint32_t)(sl - ctx->slots) + 1u) % ctx->nslots;
@@ -1794,6 +1801,7 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
         rc = found->finish(ctx, found, out);
         found->pending = false;
         found->collecting = false;
+        found->sync_owned = false;
     }
     ctx->cv.notify_all();
     return rc;
@@ -1829,7 +1837,12 @@ static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, ui
         s.bases = (const uint8_t*)a.bases + off * bstride;
         s.scalars = (const uint8_t*)a.scalars + off * a.scalar_size;
         s.raw_out = true;   // un-normalised partial: one inversion at the very end
-        if (have_pending && ctx->nslots < 2) {   // a single slot: no overlap between slices (and no waiting on ourselves)
+        bool free_slot = false;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            for (uint32_t k = 0; k < ctx->nslots; ++k) free_slot |= !ctx->slots[k].pending;
+        }
+        if (have_pending && !free_slot) {   // nothing free (a single slot, or the others are taken): collect our own slice first
             parts.resize(parts.size() + jsz);
             rc = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
             have_pending = false;
