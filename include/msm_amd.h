@@ -71,8 +71,10 @@ const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
 /* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
  * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
- * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight),
- * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default). */
+ * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight, 1..8),
+ * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default),
+ * "glv" (0 never | 1 where it pays (default) | 2 whenever it applies: the GLV schedule of BLS12-381 G1),
+ * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 
 /* ---- generic entry points -------------------------------------------------------------------- */
