@@ -130,6 +130,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
     }
 }
 
+// Two lanes per bucket (G1 kinds): a launch with few buckets -- the windows one rank of a sharded call owns, a small n -- would put a
+// single wave on each SIMD, where dependent multiply-adds issue at barely half rate.  Here lanes 2r and 2r+1 each add half of bucket
+// r's entries and the halves are joined with one DPP exchange and one addition: twice the waves for ~1/mean more work.
+template <class F>
+__global__ void __launch_bounds__(256) k_accumulate_split2(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
+                                                            const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
+                                                            const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
+                                                            TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+    static_assert(UKind<F>::type::LANES == 1, "one-lane kinds only");
+    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = gt >> 1, s = gt & 1u;
+    if (r >= nb) return;   // both lanes of a pair leave together
+    const uint32_t b = order[r], cnt = count[b], off = offset[b];
+    const uint32_t tot = min(cnt, 2u * seg), chunk = (tot + 1u) >> 1;
+    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, off + s * chunk, s ? tot - chunk : chunk);
+    BU<F> other;
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
+#pragma unroll
+        for (int k = 0; k < (int)(sizeof(BU<F>) / 4); ++k) dst[k] = pair_xchg(src[k]);
+    }
+    acc = BU<F>::add(acc, other);
+    if (s == 0) {
+        store16(buckets + (size_t)b * sizeof(BU<F>), acc);
+        if (cnt > 2u * seg) {
+            const uint32_t done = 2u * seg, extra = (cnt - done + seg - 1u) / seg;
+            uint32_t base = atomicAdd(&ctl->nwork, extra);
+            uint32_t bi = atomicAdd(&ctl->nbig, 1u);
+            biglist[bi] = make_uint4(b, base, extra, 0u);
+            for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
+        }
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
@@ -262,6 +297,12 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbet
                                                                                 (uint2*)work, (uint4*)biglist);
 }
 template <class F>
+void launch_accumulate_split2(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                              const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
+    k_accumulate_split2<F><<<(uint32_t)(((uint64_t)nb * 2 + 63) / 64), 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
+                                                                               (uint2*)work, (uint4*)biglist);
+}
+template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
                             uint32_t tail_block) {
@@ -290,6 +331,9 @@ uint32_t lanes_per_point() {
 #define MSM_INSTANTIATE_ACCUMULATE(F, VARIANT)                                                                                               \
     template void launch_accumulate<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*);
+#define MSM_INSTANTIATE_SPLIT2(F)                                                                                                            \
+    template void launch_accumulate_split2<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
+                                              uint32_t, uint8_t*, uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_TAIL(F)                                                                                                              \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
                                             uint32_t, void*, void*, void*, uint8_t*, uint32_t);
