@@ -60,7 +60,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine option (msm_amd_set_option), e.g. reduce_l=32; for experiments")
     ap.add_argument("--host-buffers", action="store_true", help="pass host memory each call (PCIe-inclusive rate; informational, never the headline value)")
     ap.add_argument("--resident-bases", action="store_true", help="with --host-buffers: keep the bases on the GPU, copy only the scalars")
-    ap.add_argument("--depth", type=int, default=0, help="calls in flight when pipelined (default 2; 4 for more than two ranks)")
+    ap.add_argument("--depth", type=int, default=0, help="calls in flight when pipelined (default 2; 4 for more than four ranks)")
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
     args = ap.parse_args()
 
@@ -141,12 +141,17 @@ def main():
         name, val = kv.split("=")
         eng.set_option(name, int(val))
 
+    xch = mdist.PartialExchange(args.curve, g, device=xdev) if world > 1 else None
+    gathering = []   # all_gathers started and not yet collected (at most one is left running behind the loop)
+
     def finish(ticket):
         out = ticket.wait()
         if world == 1:
             return out
-        # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, then the host adds them
-        return mdist.gather_and_combine(args.curve, g, out, device=xdev)
+        # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, started asynchronously; the
+        # previous call's gathered partials are collected and added on the host meanwhile
+        gathering.append(xch.submit(out))
+        return xch.result(gathering.pop(0)) if len(gathering) > 1 else None
     sync()
     t0 = time.perf_counter()
     if pipelined:
@@ -164,6 +169,8 @@ def main():
         while inflight:
             result = finish(inflight.pop(0))
             collect()
+        while gathering:
+            result = xch.result(gathering.pop(0))
     else:
         for _ in range(args.steps):
             result = step()

@@ -74,7 +74,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight, 1..8),
  * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default),
  * "glv" (0 never | 1 where it pays (default) | 2 whenever it applies: the GLV schedule of BLS12-381 G1),
- * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice). */
+ * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice),
+ * "split2" (0 = never give a bucket two lanes; default 1: G1 launches with few buckets do), "split2_nb" (bucket count below
+ * which they do, default 131072 = two waves per SIMD). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 
 /* ---- generic entry points -------------------------------------------------------------------- */

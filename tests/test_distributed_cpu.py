@@ -49,6 +49,11 @@ def _worker(rank, world, port, curve, group, n, c, q):
             for _ in range(prev * c):
                 acc = O.double(acc)
         total = mdist.gather_and_combine(curve, group, acc)
+        # the asynchronous form bench.py uses for N > 1: two exchanges in flight, collected in order
+        xch = mdist.PartialExchange(curve, group)
+        h1, h2 = xch.submit(acc), xch.submit(O.zero())
+        assert xch.result(h1) == total
+        assert xch.result(h2) == O.normalize(O.zero())
         if rank == 0:
             exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
             q.put((total == exp, total.hex()[:16]))

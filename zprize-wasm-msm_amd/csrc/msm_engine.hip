@@ -1255,6 +1255,7 @@ struct msm_amd_ctx {
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int no_split2 = 0;      // option "split2" = 0 switches the two-lanes-per-bucket accumulation of small launches off
+    uint32_t split2_nb = 2u * 1024u * 64u;   // option "split2_nb": launches with fewer buckets than this use it (default: two waves per SIMD)
     uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
@@ -1568,7 +1569,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     auto accumulate = [&](const uint32_t* ord, uint32_t nbk) {
         if constexpr (KernelField<F>::chained_variant) {
             // few buckets with enough entries each (the windows of one rank of a sharded call): two lanes per bucket
-            if (!ctx->no_split2 && (uint64_t)nbk < 2u * 1024u * 64u && mean >= 16) {
+            if (!ctx->no_split2 && nbk < ctx->split2_nb && mean >= 16) {
                 launch_accumulate_split2<FK>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
                 return;
             }
@@ -2238,6 +2239,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split2")) { ctx->no_split2 = value == 0; return 0; }
+    if (!strcmp(name, "split2_nb")) { ctx->split2_nb = value; return 0; }
     if (!strcmp(name, "slice")) {
         if (value < 1 || value > (1u << 27)) { ctx->err = "slice must be in [1, 2^27]"; return MSM_AMD_EINVAL; }
         ctx->max_slice = value;

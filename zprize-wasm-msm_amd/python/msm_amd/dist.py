@@ -14,16 +14,38 @@ import torch.distributed as dist
 from . import combine
 
 
-def gather_and_combine(curve, group, partial, device=None, process_group=None):
-    """all_gather one Jacobian partial per rank and return the normalised sum (same bytes on every rank)."""
+def _start_gather(partial, device, process_group, async_op):
     world = dist.get_world_size(process_group)
     mine = torch.frombuffer(bytearray(partial), dtype=torch.uint8)
     if device is not None:
         mine = mine.to(device)
-    bufs = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=process_group)
-    allp = b"".join(bytes(b.cpu().numpy().tobytes()) for b in bufs)
-    return combine(curve, group, allp)
+    flat = torch.empty(world * mine.numel(), dtype=torch.uint8, device=mine.device)
+    work = dist.all_gather_into_tensor(flat, mine, group=process_group, async_op=async_op)
+    return work, flat, mine
+
+
+def gather_and_combine(curve, group, partial, device=None, process_group=None):
+    """all_gather one Jacobian partial per rank (one collective into one flat tensor, one copy back) and return the
+    normalised sum (same bytes on every rank)."""
+    _, flat, _ = _start_gather(partial, device, process_group, False)
+    return combine(curve, group, flat.cpu().numpy().tobytes())
+
+
+class PartialExchange:
+    """The same exchange for a caller that keeps several sharded calls in flight: `submit` starts the all_gather of one
+    call's partial and returns at once; `result` waits for it, copies the world x 144 B back and adds them on the host.
+    The collective of call k then runs while the host collects the partial of call k+1 (bench.py, N > 1)."""
+
+    def __init__(self, curve, group, device=None, process_group=None):
+        self.curve, self.group, self.device, self.pg = curve, group, device, process_group
+
+    def submit(self, partial):
+        return _start_gather(partial, self.device, self.pg, True)
+
+    def result(self, handle):
+        work, flat, _mine = handle
+        work.wait()
+        return combine(self.curve, self.group, flat.cpu().numpy().tobytes())
 
 
 def multiexp_sharded(curve_obj, group, bases, scalars, scalar_size, n, device=None, process_group=None, jacobian_bases=False):
