@@ -652,3 +652,33 @@ def test_window_shards_sum_to_full(eng, orc, curve, group, nshards):
     exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
     parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, s, nshards) for s in range(nshards))
     assert msm_amd.combine(curve, group, parts) == exp
+
+
+def test_partial_exchange_over_rccl_one_rank(eng, orc):
+    """The exchange bench.py uses for N > 1 (msm_amd.dist.PartialExchange: asynchronous all_gather_into_tensor of the 144-byte
+    partials on the GPU, one copy back, host addition) on the RCCL backend with a world of one -- what a one-GPU box can run."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd import dist as mdist
+    curve, group, n = "bls12381", 1, 700
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, scalars = gu.random_case(curve, group, "gpu:rccl1", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        part = C.multiexp_shard(group, bases, scalars, 32, n, 0, 1)
+        xch = mdist.PartialExchange(curve, group, device=dev)
+        h1, h2 = xch.submit(part), xch.submit(part)
+        assert xch.result(h1) == exp and xch.result(h2) == exp
+        assert mdist.gather_and_combine(curve, group, part, device=dev) == exp
+    finally:
+        dist.destroy_process_group()
