@@ -231,13 +231,28 @@ MSM_D BU<F> rdbl(const BU<F>& a) {
 
 template <class F>
 __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
-                                                        uint32_t wgs_per_window, uint8_t* __restrict__ partials) {
+                                                        uint32_t wgs_per_window, uint8_t* __restrict__ partials, const uint32_t* __restrict__ offset,
+                                                        const uint32_t* __restrict__ count, uint32_t gb0, uint32_t NB) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
     constexpr uint32_t T = UKind<F>::type::LANES;
     const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, nlt = blockDim.x / T;
     uint32_t w = blockIdx.x / wgs_per_window;
     uint32_t wg = blockIdx.x % wgs_per_window;
+    {
+        // a window nothing was scattered into (the carry window above 255-bit scalars): all its buckets are infinity, and so is
+        // its sum -- the whole workgroup leaves (offsets run over the windows in order; gb0 = first bucket of this launch)
+        const uint32_t gb = gb0 + w * half;
+        const uint32_t beg = offset[gb];
+        const uint32_t end = gb + half < NB ? offset[gb + half] : offset[NB - 1] + count[NB - 1];
+        if (beg == end) {
+            if (lt == 0) {
+                BU<F> z = BU<F>::inf();
+                z.to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
+            }
+            return;
+        }
+    }
     uint32_t t = wg * nlt + lt;
     BU<F> res = BU<F>::inf();
     if (t < lanes_per_window) {
@@ -312,9 +327,11 @@ void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t*
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
-                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials) {
+                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
+                          uint32_t gb0, uint32_t NB) {
     constexpr uint32_t T = UKind<F>::type::LANES;
-    k_bucket_reduce<F><<<nparts, rblock * T, (size_t)rblock * T * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials);
+    k_bucket_reduce<F><<<nparts, rblock * T, (size_t)rblock * T * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials, offset,
+                                                                                         count, gb0, NB);
 }
 
 // bytes of one bucket in HBM (the engine sizes its bucket arrays and LDS tiles with this)
@@ -338,7 +355,8 @@ uint32_t lanes_per_point() {
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
                                             uint32_t, void*, void*, void*, uint8_t*, uint32_t);
 #define MSM_INSTANTIATE_REDUCE(F)                                                                                                            \
-    template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*); \
+    template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*, const uint32_t*, \
+                                          const uint32_t*, uint32_t, uint32_t); \
     template size_t bucket_bytes<F>();                                                                                                        \
     template uint32_t lanes_per_point<F>();
 #define MSM_INSTANTIATE_TAIL_AND_REDUCE(F) MSM_INSTANTIATE_TAIL(F) MSM_INSTANTIATE_REDUCE(F)

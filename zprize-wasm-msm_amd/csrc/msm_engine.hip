@@ -51,7 +51,8 @@ void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t*
                             uint32_t tail_block);
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
-                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials);
+                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
+                          uint32_t gb0, uint32_t NB);
 // field flavour used inside the bucket kernels: G1 fields expand their multiplies inline
 template <class F>
 size_t bucket_bytes();   // bytes of one bucket in HBM (the bucket kernels keep their own representation, curve_u.hpp)
@@ -1638,11 +1639,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     uint8_t* partials = (uint8_t*)sl->d_partials.p;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
-    launch_bucket_reduce<FK>(sb, nparts0, p0.rblock, buckets, g.half, p0.L, p0.lanes, p0.wgs, partials);
+    launch_bucket_reduce<FK>(sb, nparts0, p0.rblock, buckets, g.half, p0.L, p0.lanes, p0.wgs, partials, offset, count, 0, NB);
     if (nparts1) {
         hipStream_t sc = sl->stream_c;
         HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
-        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * BSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ);
+        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * BSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ, offset,
+                                 count, split, NB);
         HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
         HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
     }
