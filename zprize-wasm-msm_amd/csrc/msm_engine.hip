@@ -1246,6 +1246,7 @@ struct msm_amd_ctx {
     std::condition_variable cv;
     hipStream_t stream = nullptr;     // A: bucket accumulation (the ALU-bound stage), in call order
     hipStream_t stream_s = nullptr;   // S: transfers + bucket sort of the NEXT call, under the current call's accumulation
+    hipStream_t stream_s2 = nullptr;  // S2: the same for calls whose accumulation is small (few owned windows of a sharded call, small n)
     static constexpr uint32_t MAX_SLOTS = 8;
     Slot slots[MAX_SLOTS];
     uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..8)
@@ -1368,7 +1369,21 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         return 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream_s;   // everything up to the sorted index lists runs on stream S
+    // everything up to the sorted index lists runs on stream S -- or S2 when the accumulation will be small: such calls run their
+    // accumulation and reduction on their slot's own stream, several of them in flight, and the ~ten short sort kernels of the next
+    // call must not queue behind one of those in a shared hardware queue (8-way shard of n = 2^20: 0.77 -> 0.56 ms per call with
+    // both measures; calls with a full-size accumulation were 3-8 % slower on S2, hence two streams)
+    bool small_est;
+    {
+        const uint32_t c0 = pick_window_bits(a.n, a.nbits, ctx->force_c), w0 = a.nbits / c0 + 1;
+        small_est = (uint64_t)((w0 + a.nshards - 1) / a.nshards) << (c0 - 1) < 2u * 1024u * 64u;
+    }
+    if (small_est && !ctx->stream_s2) {
+        // created on first use: the mere existence of a stream of another priority re-partitions the hardware queues and cost calls
+        // with a full-size accumulation ~5 % (measured); of another priority because only such streams never share a queue with S/A/B
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_s2, hipStreamNonBlocking, 1));
+    }
+    hipStream_t st = small_est ? ctx->stream_s2 : ctx->stream_s;
     const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
     const bool dev_bases = dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
     const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
@@ -1546,7 +1561,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // A SMALL accumulation (fewer than two waves per SIMD: few owned windows of a sharded call, small n) cannot fill the
     // chip by itself, so it goes to the slot's own stream instead and may overlap the accumulations of the other calls in flight.
     const bool small_acc = NB < 2u * 1024u * 64u && !split_mode;
-    st = small_acc ? sl->stream_c : ctx->stream;
+    st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
     HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
     HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
     // segment length: mean bucket population + 8 standard deviations of a Poisson bucket, at least 32: random inputs
@@ -1780,6 +1795,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
     if (rc) {
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream_s);
+        if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamSynchronize(sl->stream_c);
         (void)hipStreamSynchronize(sl->stream_b);
@@ -2215,6 +2231,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
+    if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
     (void)hipStreamSynchronize(ctx->stream);
     for (Slot& sl : ctx->slots) {
         if (sl.stream_b) {
@@ -2233,6 +2250,7 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
             if (e) (void)hipEventDestroy(e);
     }
     if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
+    if (ctx->stream_s2) (void)hipStreamDestroy(ctx->stream_s2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
