@@ -64,6 +64,14 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
     args = ap.parse_args()
 
+    # N > 1: RCCL (through torch's stream pools) creates dozens of HIP streams before the engine creates its own, and HIP maps all of
+    # them onto four hardware queues by default; the engine's sort / accumulation / reduction streams then share queues they should
+    # not (measured on one GPU with a one-rank RCCL group: 1.15 -> 1.42 ms per call for a 4-way shard, 1.57 -> 1.96 for 2-way).  Eight
+    # hardware queues restore the figures (profiles/r01_rccl_hw_queues.log).  Must be set before the HIP runtime starts; not for
+    # N = 1, where four queues are the faster setting.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
     import torch
     import torch.distributed as dist
     import msm_amd

@@ -21,9 +21,37 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--rccl", choices=["none", "before", "after"], default="none",
+                    help="initialise a one-rank RCCL process group (and run one all_gather) before / after the engine is created: "
+                         "the streams RCCL creates shift the stream-to-hardware-queue mapping of whatever is created after them")
     a = ap.parse_args()
     n = 1 << a.logn
+
+    def rccl():
+        import socket
+        import torch
+        import torch.distributed as dist
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        x = torch.zeros(144, dtype=torch.uint8, device=dev)
+        y = torch.empty(144, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(y, x)
+        torch.cuda.synchronize()
+
+    if a.rccl != "none":
+        import torch   # torch's HIP runtime must be up before the engine library loads its own (otherwise torch finds no GPU)
+        torch.cuda.set_device(0)
+        torch.zeros(1, device="cuda")
+    if a.rccl == "before":
+        rccl()
     eng = msm_amd.Engine(0)
+    if a.rccl == "after":
+        rccl()
     eng.set_option("slots", a.depth)
     for kv in a.opt:
         k, v = kv.split("=")
