@@ -69,7 +69,10 @@ def main():
     # not (measured on one GPU with a one-rank RCCL group: 1.15 -> 1.42 ms per call for a 4-way shard, 1.57 -> 1.96 for 2-way).  Eight
     # hardware queues restore the figures (profiles/r01_rccl_hw_queues.log).  Must be set before the HIP runtime starts; not for
     # N = 1, where four queues are the faster setting.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # MSM_BENCH_FORCE_DIST=1 takes the N > 1 code path with a world of one (RCCL group, window shard 0 of 1, all_gather of one
+    # partial): the whole multi-GPU flow rehearsed on a one-GPU box
+    force_dist = os.environ.get("MSM_BENCH_FORCE_DIST", "") == "1"
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or force_dist:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     import torch
@@ -78,6 +81,7 @@ def main():
     from msm_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    sharded = world > 1 or force_dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # MSM_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share GPUs
@@ -85,8 +89,9 @@ def main():
     backend = os.environ.get("MSM_BENCH_BACKEND", "nccl")
     ngpu = torch.cuda.device_count()
     gpu_index = local_rank if backend == "nccl" else local_rank % max(1, ngpu)
-    if world > 1:
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         torch.cuda.set_device(gpu_index)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", gpu_index))
@@ -119,14 +124,14 @@ def main():
     def step():
         if args.host_buffers:
             return C._multiexp(g, 0, pts if args.resident_bases else h_pts, h_sc, 32, n)
-        if world == 1:
+        if not sharded:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
         # windows sharded over the ranks; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
         return mdist.multiexp_sharded(C, g, pts, d_scalars, 32, n, device=xdev)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -149,12 +154,12 @@ def main():
         name, val = kv.split("=")
         eng.set_option(name, int(val))
 
-    xch = mdist.PartialExchange(args.curve, g, device=xdev) if world > 1 else None
+    xch = mdist.PartialExchange(args.curve, g, device=xdev) if sharded else None
     gathering = []   # all_gathers started and not yet collected (at most one is left running behind the loop)
 
     def finish(ticket):
         out = ticket.wait()
-        if world == 1:
+        if not sharded:
             return out
         # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, started asynchronously; the
         # previous call's gathered partials are collected and added on the host meanwhile
@@ -167,7 +172,7 @@ def main():
         # step i+1 (stream A); every step is waited for inside the timed region
         inflight = []
         for _ in range(args.steps):
-            if world == 1:
+            if not sharded:
                 inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
             else:
                 inflight.append(C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
@@ -185,14 +190,14 @@ def main():
             collect()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     # two more calls, one at a time and outside the timed region: stage durations without the other call's kernels
     # running beside them (under pipelining the event intervals of a stage include whatever shares the GPU with it)
     iso = {}
-    if pipelined and world == 1:
+    if pipelined and not sharded:
         for _ in range(2):
             step()
             sync()
@@ -239,7 +244,7 @@ def main():
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
-                       "parallelism": "1 GPU" if world == 1 else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
+                       "parallelism": "1 GPU" if not sharded else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
             "roofline": {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
@@ -267,12 +272,12 @@ def main():
             "stages_ms_one_call_at_a_time": iso if iso else None,
             "result_x_prefix": result[:8].hex(),
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args, pts, sc_host, n, result)
         print(json.dumps(out), flush=True)
     pts.free()
     eng.close()
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 
