@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--dummy-streams", type=int, default=0,
+                    help="create this many idle HIP streams before the engine (shifts the stream-to-hardware-queue mapping: DESIGN.md section 7)")
     ap.add_argument("--rccl", choices=["none", "before", "after"], default="none",
                     help="initialise a one-rank RCCL process group (and run one all_gather) before / after the engine is created: "
                          "the streams RCCL creates shift the stream-to-hardware-queue mapping of whatever is created after them")
@@ -49,6 +51,15 @@ def main():
         torch.zeros(1, device="cuda")
     if a.rccl == "before":
         rccl()
+    if a.dummy_streams:
+        import ctypes
+        msm_amd.load_library()                      # brings the HIP runtime in; the handle below is the same instance
+        hip = ctypes.CDLL("libamdhip64.so")
+        keep = []
+        for _ in range(a.dummy_streams):
+            h = ctypes.c_void_p()
+            assert hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) == 0   # hipStreamNonBlocking
+            keep.append(h)
     eng = msm_amd.Engine(0)
     if a.rccl == "after":
         rccl()
