@@ -78,6 +78,10 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * "split2" (0 = never give a bucket two lanes; default 1: G1 launches with few buckets do), "split2_nb" (bucket count below
  * which they do, default 131072 = two waves per SIMD). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
+/* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
+ * hardware queue (their kernels serialise).  HIP maps streams onto hardware queues in creation order across the whole process, and
+ * the engine's throughput depends on that mapping. */
+int msm_amd_debug_stream_sharing(msm_amd_ctx *ctx, uint8_t *out);
 
 /* ---- generic entry points -------------------------------------------------------------------- */
 /* R = sum_i scalar_i * base_i                                 (build_multiexp.js:251-371) */

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[])
     ap.add_argument("--dummy-streams", type=int, default=0,
                     help="create this many idle HIP streams before the engine (shifts the stream-to-hardware-queue mapping: DESIGN.md section 7)")
+    ap.add_argument("--torch-first", action="store_true", help="initialise torch's GPU context (null stream) before the engine, as bench.py does")
+    ap.add_argument("--sharing", action="store_true", help="print which of the engine's streams share a hardware queue (msm_amd_debug_stream_sharing)")
     ap.add_argument("--rccl", choices=["none", "before", "after"], default="none",
                     help="initialise a one-rank RCCL process group (and run one all_gather) before / after the engine is created: "
                          "the streams RCCL creates shift the stream-to-hardware-queue mapping of whatever is created after them")
@@ -45,7 +47,7 @@ def main():
         dist.all_gather_into_tensor(y, x)
         torch.cuda.synchronize()
 
-    if a.rccl != "none":
+    if a.rccl != "none" or a.torch_first:
         import torch   # torch's HIP runtime must be up before the engine library loads its own (otherwise torch finds no GPU)
         torch.cuda.set_device(0)
         torch.zeros(1, device="cuda")
@@ -64,6 +66,20 @@ def main():
     if a.rccl == "after":
         rccl()
     eng.set_option("slots", a.depth)
+    if a.sharing:
+        import ctypes
+        m = (ctypes.c_uint8 * 121)()
+        eng.L.msm_amd_debug_stream_sharing.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert eng.L.msm_amd_debug_stream_sharing(eng.ctx, m) == 0
+        names = ["A", "S", "B0", "C0", "B1", "C1", "B2", "C2", "B3", "C3", "null"]
+        groups, seen = [], set()
+        for i in range(11):
+            if i in seen:
+                continue
+            g = [j for j in range(11) if m[i * 11 + j]]
+            seen.update(g)
+            groups.append("+".join(names[j] for j in g))
+        print("streams per hardware queue:", "  ".join(groups))
     for kv in a.opt:
         k, v = kv.split("=")
         eng.set_option(k, int(v))

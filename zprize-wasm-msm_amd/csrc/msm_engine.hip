@@ -2194,6 +2194,76 @@ static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* 
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
+// One wave that spins for `ticks` of the 100-MHz wall clock: the probe of the stream calibration below and of
+// msm_amd_debug_stream_sharing.
+__global__ void k_spin(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// true when kernels on a and b serialise, i.e. the two streams were mapped onto the same hardware queue
+static bool streams_serialise(hipStream_t a, hipStream_t b) {
+    const uint64_t ticks = 15000;   // 0.15 ms each: ~0.17 ms together on different queues, ~0.32 ms on a shared one
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        auto t0 = std::chrono::steady_clock::now();
+        k_spin<<<1, 64, 0, a>>>(ticks);
+        k_spin<<<1, 64, 0, b>>>(ticks);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < 245.0) return false;   // concurrent (a slow verdict is taken twice before it is believed)
+    }
+    return true;
+}
+
+// HIP maps the streams of a process onto a few hardware queues (four by default), by creation order and by what the process created
+// before -- and streams on one queue serialise.  Which of the engine's streams share a queue decides its throughput (n = 2^20, two
+// calls in flight: 2.7-2.9 ms per call when A, S, B0 and B1 sit on four queues; 3.1-3.3 when A shares with S; 3.4-3.5 when A shares
+// with B1; 3.6-3.75 when S shares with a B: profiles/r01_stream_queue_layouts.log).  So the context does not trust the creation
+// order: it finds the queue classes of the streams it created (probe above, ~10 ms) and deals them out so that the streams that work
+// side by side sit on different queues: A, S, B0, B1 on four classes; B2 with A and B3 with S (when four sharded calls are in flight
+// A and S idle: their accumulations run on the B streams, their sorts on S2).  MSM_AMD_NO_CALIBRATE=1 keeps the creation order.
+static void calibrate_streams(msm_amd_ctx* ctx) {
+    if (getenv("MSM_AMD_NO_CALIBRATE")) return;
+    std::vector<hipStream_t> all = {ctx->stream, ctx->stream_s};
+    for (Slot& sl : ctx->slots) {
+        all.push_back(sl.stream_b);
+        all.push_back(sl.stream_c);
+    }
+    k_spin<<<1, 64, 0, all[0]>>>(100);   // loads the code object before anything is timed
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    std::vector<std::vector<hipStream_t>> cls;
+    for (hipStream_t st : all) {
+        bool placed = false;
+        for (auto& c : cls)
+            if (streams_serialise(c[0], st)) {
+                c.push_back(st);
+                placed = true;
+                break;
+            }
+        if (!placed) cls.push_back({st});
+    }
+    (void)hipGetLastError();
+    if (cls.size() < 2) return;
+    const size_t nc = cls.size();
+    std::vector<hipStream_t> rest;
+    auto take = [&](size_t c) -> hipStream_t {
+        for (size_t k = 0; k < nc; ++k) {   // the wanted class, else the next one that still has a stream
+            auto& v = cls[(c + k) % nc];
+            if (!v.empty()) {
+                hipStream_t st = v.back();
+                v.pop_back();
+                return st;
+            }
+        }
+        return nullptr;
+    };
+    ctx->stream = take(0);
+    ctx->stream_s = take(1);
+    const size_t nslots = sizeof(ctx->slots) / sizeof(ctx->slots[0]);
+    for (size_t k = 0; k < nslots; ++k) ctx->slots[k].stream_b = take((2 + k) % nc);
+    for (size_t k = 0; k < nslots; ++k) ctx->slots[k].stream_c = take((2 + k) % nc);
+}
+
 int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (!out_ctx) return MSM_AMD_EINVAL;
     *out_ctx = nullptr;
@@ -2223,6 +2293,7 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
                 return MSM_AMD_EHIP;
             }
     }
+    calibrate_streams(ctx);
     *out_ctx = ctx;
     return MSM_AMD_OK;
 }
@@ -2256,6 +2327,37 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
 }
 
 const char* msm_amd_last_error(const msm_amd_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// Diagnostic: which of the context's streams serialise with each other, i.e. were mapped onto the same hardware queue (DESIGN.md
+// section 7).  Streams 0..10 = A, S, B0, C0, B1, C1, B2, C2, B3, C3 and the process's null stream.  A one-wave kernel that spins for ~0.3 ms is launched on two
+// streams at once: together they take ~0.3 ms on different queues, ~0.6 ms on a shared one.  out[i*11+j] = 1 when i and j serialise.
+int msm_amd_debug_stream_sharing(msm_amd_ctx* ctx, uint8_t* out) {
+    if (!ctx || !out) return MSM_AMD_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st[11] = {ctx->stream, ctx->stream_s};
+    st[10] = nullptr;
+    for (int k = 0; k < 4; ++k) {
+        st[2 + 2 * k] = ctx->slots[k].stream_b;
+        st[3 + 2 * k] = ctx->slots[k].stream_c;
+    }
+    const uint64_t ticks = 30000;   // wall_clock64 counts at 100 MHz: 0.3 ms
+    k_spin<<<1, 64, 0, st[0]>>>(1000);
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (int i = 0; i < 11; ++i)
+        for (int j = 0; j < 11; ++j) out[i * 11 + j] = i == j;
+    for (int i = 0; i < 11; ++i)
+        for (int j = i + 1; j < 11; ++j) {
+            auto t0 = std::chrono::steady_clock::now();
+            k_spin<<<1, 64, 0, st[i]>>>(ticks);
+            k_spin<<<1, 64, 0, st[j]>>>(ticks);
+            HIPCHK(ctx, hipStreamSynchronize(st[i]));
+            HIPCHK(ctx, hipStreamSynchronize(st[j]));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            out[i * 11 + j] = out[j * 11 + i] = us > 470.0;
+        }
+    return MSM_AMD_OK;
+}
 
 int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!ctx || !name) return MSM_AMD_EINVAL;
