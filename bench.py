@@ -24,6 +24,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "zprize-wasm-msm
 
 R_BLS = 52435875175126190479447740508185965837690552500527637822603658699938581184513
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TMADS = 36.3         # v_mad_u64_u32 per second, measured at 2.4 GHz (profiles/r01_valu_rates_microbench.txt)
+# v_mad_u64_u32 per XYZZ mixed addition in the bucket kernels (6 products + 2 squarings + one fused two-product reduction):
+# NL-limb product = 2 NL^2, squaring = NL(NL+1)/2 + NL^2, fused = 3 NL^2; BLS12-381: NL = 14, BN254: NL = 9 (field_u.hpp)
+MADS_PER_ADD = {("bls12381", 1): 6 * 392 + 2 * 301 + 588, ("bn128", 1): 6 * 162 + 2 * 126 + 243}
 
 
 def uniform_scalars_mod_r(n, seed):
@@ -47,6 +51,45 @@ def uniform_scalars_mod_r(n, seed):
     return out.view(np.uint8).reshape(n, 32)
 
 
+def launch_ranks(n):
+    """Parent of a `python bench.py --gpus N` run: N child ranks (one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, exactly what torch.distributed.run would set), rank 0's stdout forwarded, exit code = the worst child's.
+    The parent itself never touches the GPU (torch.cuda.device_count() only reads the driver's device list on this image)."""
+    import socket
+    import subprocess
+    backend = os.environ.get("MSM_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and os.environ.get("MSM_BENCH_LAUNCH_ONLY", "") != "1":
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py: --gpus {n} asks for {n} ranks over RCCL but this node shows {have} GPU(s); "
+                  "(MSM_BENCH_BACKEND=gloo rehearses the N > 1 path with ranks sharing GPUs)", file=sys.stderr)
+            return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("MSM_BENCH_LAUNCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            code = p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            code = -1
+        if code != 0 and rc == 0:
+            rc = code if code > 0 else 1
+            for q in procs:          # one rank failed or hung: the others would wait in the barrier for ever
+                if q.poll() is None:
+                    q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +109,17 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
     args = ap.parse_args()
 
+    # --gpus N > 1 without a launcher around us (python bench.py --gpus N): start the N ranks ourselves.  This happens before torch,
+    # the engine library or anything else that touches the GPU is imported: a process that has initialised the GPU must not exec or
+    # fork workers.  Under `python -m torch.distributed.run` (the driver's form) WORLD_SIZE is already set and this is skipped.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch_ranks(args.gpus))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to run a mislabelled job")
+
     # N > 1: RCCL (through torch's stream pools) creates dozens of HIP streams before the engine creates its own, and HIP maps all of
     # them onto four hardware queues by default; the engine's sort / accumulation / reduction streams then share queues they should
     # not (measured on one GPU with a one-rank RCCL group: 1.15 -> 1.42 ms per call for a 4-way shard, 1.57 -> 1.96 for 2-way).  Eight
@@ -74,6 +128,10 @@ def main():
     # MSM_BENCH_FORCE_DIST=1 takes the N > 1 code path with a world of one (RCCL group, window shard 0 of 1, all_gather of one
     # partial): the whole multi-GPU flow rehearsed on a one-GPU box
     force_dist = os.environ.get("MSM_BENCH_FORCE_DIST", "") == "1"
+    if os.environ.get("MSM_BENCH_LAUNCH_ONLY", "") == "1":     # launcher test (CPU): say who we are and leave before any GPU use
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "master": os.environ.get("MASTER_ADDR"), "argv_gpus": args.gpus}), flush=True)
+        return
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or force_dist:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -204,6 +262,15 @@ def main():
             step()
             sync()
             iso = dict(eng.timings())
+    # latency: individually timed synchronous calls (wall time of one MSM call, median of >= 5 runs)
+    lat_ms = []
+    if not sharded and not args.host_buffers:
+        for _ in range(7):
+            sync()
+            t1 = time.perf_counter()
+            step()
+            lat_ms.append((time.perf_counter() - t1) * 1e3)
+        lat_ms.sort()
     geom = eng.geometry()
     stages = {k: v / args.steps for k, v in stage_acc.items()}
 
@@ -216,9 +283,12 @@ def main():
         alg_bytes = geom["entries"] * (aff + 4)
         acc_ms = stages.get("accumulate", 0.0)
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        # HBM bytes of one k_accumulate launch from the hardware counters (rocprofv3 --pmc, its own run: profiles/pmc_accumulate.json);
+        # only quoted for the workload it was measured on
         traffic = None
+        headline = (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["c"] == 16 and geom["windows"] == 17 and not sharded
         pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
-        if os.path.exists(pmc):
+        if headline and os.path.exists(pmc):
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -231,11 +301,12 @@ def main():
         sc_bytes = n * 32 + geom["entries"] * 4
         sc_traffic = None
         pmc_s = os.path.join(ROOT, "profiles", "pmc_scatter.json")
-        if os.path.exists(pmc_s) and (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["windows"] == 17:
+        if os.path.exists(pmc_s) and headline:
             try:
                 sc_traffic = json.load(open(pmc_s)).get("hbm_bytes_per_call")
             except Exception:
                 sc_traffic = None
+        mads = MADS_PER_ADD.get((args.curve, g))
         out = {
             "metric": "BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}",
@@ -247,29 +318,40 @@ def main():
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
                        "parallelism": "1 GPU" if not sharded else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
-            "roofline": {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
-                         "avg_launch_ms_one_call_at_a_time": acc_iso,
-                         "achieved_one_call_at_a_time": (alg_bytes / (acc_iso * 1e-3) / 1e9) if acc_iso > 0 else None},
-            "roofline_scatter": {"kernels": "k_histogram + scan/order + k_scatter (HBM-bound stage)", "bound": "hbm",
+            "mode": (f"pipelined({depth}): {depth} calls in flight, every call collected inside the timed region" if pipelined else "one call at a time"),
+            # the dominant kernel is integer-ALU bound: its roofline is the VALU issue rate of v_mad_u64_u32 (MADS_PER_ADD of them per
+            # bucket addition, field_u.hpp / curve_u.hpp).  Peak: measured on this chip with tools/microbench/valu_rates.hip
+            # (profiles/r01_valu_rates_microbench.txt: 36.3 T mad/s at 2.4 GHz -- the guide lists no integer multiply-add peak; the chip
+            # clocks this kernel at ~1.9-2.0 GHz, which puts the practical ceiling of `frac` at ~0.65-0.7).  The HBM fraction on
+            # algorithmic bytes (entries x (affine point + 4-byte index)) is kept beside it: small by construction.
+            "roofline": ({"kernel": "k_accumulate (bucket accumulation)", "bound": "valu",
+                          "achieved": geom["entries"] * mads / (acc_ms * 1e-3) / 1e12, "peak": VALU_PEAK_TMADS, "unit": "T mad/s",
+                          "frac": geom["entries"] * mads / (acc_ms * 1e-3) / 1e12 / VALU_PEAK_TMADS,
+                          "frac_one_call_at_a_time": (geom["entries"] * mads / (acc_iso * 1e-3) / 1e12 / VALU_PEAK_TMADS) if acc_iso > 0 else None,
+                          "mads_per_bucket_addition": mads,
+                          "peak_source": "measured: tools/microbench/valu_rates.hip, profiles/r01_valu_rates_microbench.txt (v_mad_u64_u32, 2.4 GHz)",
+                          "traffic": traffic, "traffic_note": "HBM bytes per launch from rocprofv3 --pmc (FETCH_SIZE doubled as the guide prescribes for 16-B streaming loads; on this 16-B-per-lane GATHER the factor lies between 1 and 2, see DESIGN.md 5), measured on this workload only",
+                          "avg_launch_ms": acc_ms, "avg_launch_ms_one_call_at_a_time": acc_iso,
+                          "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_launch": alg_bytes,
+                                  "achieved_one_call_at_a_time": (alg_bytes / (acc_iso * 1e-3) / 1e9) if acc_iso > 0 else None}}
+                         if mads and acc_ms > 0 else
+                         {"kernel": "k_accumulate (bucket accumulation, integer-ALU bound)", "bound": "hbm", "achieved": achieved,
+                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
+                          "avg_launch_ms_one_call_at_a_time": acc_iso}),
+            "roofline_scatter": {"kernels": "digits + coarse histogram + scan + coarse scatter + fine sort + population order (HBM-bound stage)", "bound": "hbm",
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,
-                                 # what the hardware counters say these kernels move (multi-pass partition: ~7x the algorithmic bytes)
+                                 # what the hardware counters say these kernels move (profiles/pmc_scatter.json), this workload only
                                  "traffic": sc_traffic,
                                  "avg_ms_one_call_at_a_time": sc_iso,
                                  "frac_one_call_at_a_time": (sc_bytes / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_iso > 0 else None,
                                  "traffic_frac_of_peak": (sc_traffic / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_iso > 0) else None},
-            # the dominant kernel is integer-ALU bound: its own roofline is the VALU issue rate.  3542 v_mad_u64_u32 per bucket
-            # addition (6 products x 392 + one fused two-product reduction 588 + 2 squarings x 301, field_u.hpp) against the
-            # measured full-rate peak of 36.3 T mad/s at 2.4 GHz (profiles/r01_valu_rates_microbench.txt); the mads are ~75 % of
-            # the kernel's VALU instructions (profiles/pmc_accumulate.json: SQ_INSTS_VALU) and the chip clocks this kernel
-            # at ~1.95 GHz (GRBM_GUI_ACTIVE), so ~0.6 is the practical ceiling of this fraction.
-            "roofline_valu": ({"kernel": "k_accumulate", "achieved": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12, "peak": 36.3, "unit": "T mad/s",
-                               "frac": geom["entries"] * 3542 / (acc_ms * 1e-3) / 1e12 / 36.3,
-                               "frac_one_call_at_a_time": (geom["entries"] * 3542 / (acc_iso * 1e-3) / 1e12 / 36.3) if acc_iso > 0 else None}
-                              if acc_ms > 0 and args.curve == "bls12381" and g == 1 else None),
+            "latency": ({"what": "wall time of one synchronous msm_amd_multiexp call, inputs resident, nothing else in flight",
+                         "runs": len(lat_ms), "median_ms": lat_ms[len(lat_ms) // 2], "min_ms": lat_ms[0], "max_ms": lat_ms[-1],
+                         "pairs_per_s_at_median": n / (lat_ms[len(lat_ms) // 2] * 1e-3)} if lat_ms else None),
             "stages_ms": stages,
             "stages_ms_one_call_at_a_time": iso if iso else None,
             "result_x_prefix": result[:8].hex(),
@@ -321,6 +403,11 @@ def cpu_baseline(args, pts, sc_host, n, gpu_result):
     O.multiexp_affine(bases[:m1 * asz], sc[:m1 * 32], 32, m1)
     dt1 = time.perf_counter() - t1
     return {"value": m / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "note": "kind 'port' = oracle/oracle.c, the C restatement of the reference schedule (64-bit limbs, native code): several times FASTER "
+                    "than the reference's own WASM, whose rate (BASELINE.md section 2: g1m_multiexpAffine under Node v12, ONE thread of an 8-vCPU "
+                    "Intel Xeon @ 2.10 GHz build container, n = 2^16) was 1.06e4 pairs/s; the .wasm cannot travel to this box, so the port is the "
+                    "(tougher) baseline timed here",
+            "reference_wasm_in_container": {"value": 1.06e4, "unit": "pairs/s", "cores": 1, "n": 65536, "hardware": "Intel Xeon @ 2.10 GHz (build container), Node v12.22.9", "source": "BASELINE.md section 2"},
             "sample": f"first {m} pairs of the same workload: {nchunks} window tasks (c = {c}, the reference's schedule) of the oracle's "
                       f"multiexpAffine_chunk on {threads} threads + Horner combine, {dt:.1f} s",
             "single_thread_value": m1 / dt1, "single_thread_sample": f"first {m1} pairs, one call of the oracle's multiexpAffine, {dt1:.1f} s",

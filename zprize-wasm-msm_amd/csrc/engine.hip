@@ -1,0 +1,1019 @@
+// engine.hip -- MI355X (gfx950) Pippenger multi-scalar multiplication behind the C ABI of
+// include/msm_amd.h.
+//
+// What the reference does (wasmcurves/src/build_multiexp.js): for each c-bit window, walk the n
+// (scalar, base) pairs sequentially, add each base into table[digit-1] with g1m_addMixed
+// (:186-233), collapse the table by recursive halving (:373-461), and Horner-combine the windows
+// (:310-369).  One thread, unsigned digits, table in WASM linear memory.
+//
+// What this engine does instead (same group element, different schedule):
+//   1. digits      one thread per scalar: signed radix-2^c recoding of the requested bit range
+//                  (digit in [-2^(c-1), 2^(c-1)]), histogram of bucket populations
+//   2. scan/order  exclusive scan of the histogram; buckets ordered by population so that the
+//                  64 lanes of a wavefront run the same trip count
+//   3. scatter     radix-c bucket scatter: point indices (sign in bit 31) grouped by bucket
+//   4. accumulate  one lane per bucket: gather affine points, XYZZ mixed additions (curve.hpp)
+//   5. reduce      per window sum_k k*B_k: short running sums per lane, a small scalar
+//                  multiplication by the lane's bucket offset, LDS tree reduction per workgroup
+//   6. combine     window partials (a few KB) go to the host, which Horner-combines them and
+//                  normalises the result (the serial doubling chain is latency-, not throughput-bound)
+#include "engine_ctx.hpp"
+#include "sort_kernels.hpp"
+
+namespace msm {
+
+
+// launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
+template <class F, int VARIANT>
+void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+template <class F>
+void launch_accumulate_split2(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                              const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+template <class F>
+void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
+                            const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
+                            uint32_t tail_block);
+template <class F>
+void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
+                          uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
+                          uint32_t gb0, uint32_t NB);
+// field flavour used inside the bucket kernels: G1 fields expand their multiplies inline
+template <class F>
+size_t bucket_bytes();   // bytes of one bucket in HBM (the bucket kernels keep their own representation, curve_u.hpp)
+template <class F>
+uint32_t lanes_per_point();   // threads that share one point in the bucket kernels (2 for G2: Fp2 components on lane pairs)
+template <class F>
+struct KernelField {
+    using type = F;
+    static constexpr bool chained_variant = false;
+};
+template <class P>
+struct KernelField<Fp<P, false>> {
+    using type = Fp<P, true>;
+    static constexpr bool chained_variant = true;   // bucket_g1_*_acc.hip
+};
+
+}  // namespace msm
+
+// msm_amd_last_error: a per-thread copy taken under the error lock (the stored string may be rewritten by another thread)
+static std::mutex g_err_mu;
+void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    ctx->err = msg;
+}
+
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
+    uint32_t c;
+    if (forced) {
+        c = forced;
+    } else {
+        // measured on MI355X (profiles/r01_sweep_window_bits.log): the bucket reduction costs ~1.1 ms whatever n is
+        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits.
+        c = n >= 4096 ? 16 : 8;
+    }
+    if (c > nbits) c = nbits;
+    if (c < 1) c = 1;
+    if (c > 16) c = 16;   // 16-bit digit codes, 15-bit bucket index
+    return c;
+}
+
+struct RunArgs {
+    const void* bases;
+    const void* scalars;
+    uint32_t scalar_size, n, flags;
+    uint32_t bit_lo, nbits;   // scalar bit range
+    uint32_t shard, nshards;
+    bool raw_out;             // un-normalised Jacobian partial (multi-GPU shard)
+};
+
+template <class F>
+static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out);
+
+template <class F>
+static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
+    using X = XYZZ<F>;
+    using FK = typename KernelField<F>::type;
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);   // packed images
+    const size_t BSZ = bucket_bytes<FK>();                                               // one bucket in HBM
+    sl->trivial = false;
+    sl->raw_out = a.raw_out;
+    sl->finish = &finish_msm<F>;
+    if (a.n == 0 || a.nbits == 0) {
+        sl->trivial = true;
+        return 0;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // everything up to the sorted index lists runs on stream S -- or S2 when the accumulation will be small: such calls run their
+    // accumulation and reduction on their slot's own stream, several of them in flight, and the ~ten short sort kernels of the next
+    // call must not queue behind one of those in a shared hardware queue (8-way shard of n = 2^20: 0.77 -> 0.56 ms per call with
+    // both measures; calls with a full-size accumulation were 3-8 % slower on S2, hence two streams)
+    bool small_est;
+    {
+        const uint32_t c0 = pick_window_bits(a.n, a.nbits, ctx->force_c), w0 = a.nbits / c0 + 1;
+        small_est = (uint64_t)((w0 + a.nshards - 1) / a.nshards) << (c0 - 1) < 2u * 1024u * 64u;
+    }
+    if (small_est && !ctx->stream_s2) {
+        // created on first use: the mere existence of a stream of another priority re-partitions the hardware queues and cost calls
+        // with a full-size accumulation ~5 % (measured); of another priority because only such streams never share a queue with S/A/B
+        HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_s2, hipStreamNonBlocking, 1));
+    }
+    hipStream_t st = small_est ? ctx->stream_s2 : ctx->stream_s;
+    const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const bool dev_bases = dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
+    const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
+    const size_t base_bytes = (size_t)a.n * (jac ? JSZ : ASZ);
+    const size_t scalar_bytes = (size_t)a.n * a.scalar_size;
+
+    const uint8_t* d_bases;
+    const uint8_t* d_scalars;
+    if (dev_bases) {
+        if (((uintptr_t)a.bases & 15) != 0) {
+            msm_set_err(ctx, "device bases pointer must be 16-byte aligned");
+            return MSM_AMD_EINVAL;
+        }
+        d_bases = (const uint8_t*)a.bases;
+    } else {
+        if (int rc = ensure(ctx, sl->d_bases, base_bytes)) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(sl->d_bases.p, a.bases, base_bytes, hipMemcpyHostToDevice, st));
+        d_bases = (const uint8_t*)sl->d_bases.p;
+    }
+    if (dev_scalars) {
+        d_scalars = (const uint8_t*)a.scalars;
+    } else {
+        if (int rc = ensure(ctx, sl->d_scalars, scalar_bytes + 8)) return rc;
+        HIPCHK(ctx, hipMemcpyAsync(sl->d_scalars.p, a.scalars, scalar_bytes, hipMemcpyHostToDevice, st));
+        d_scalars = (const uint8_t*)sl->d_scalars.p;
+    }
+
+    Geom g;
+    g.n = a.n;
+    g.scalar_size = a.scalar_size;
+    g.bit_lo = a.bit_lo;
+    g.nbits = a.nbits;
+    g.c = pick_window_bits(a.n, a.nbits, ctx->force_c);
+    g.W = a.nbits / g.c + 1;
+    g.half = 1u << (g.c - 1);
+    g.shard = a.shard;
+    g.nshards = a.nshards;
+    // GLV path: 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_digits_glv).  Same number of bucket
+    // additions, half the buckets.  It pays where the bucket reduction dominates (n <= 2^17: 8-15 % per call); from 2^18 up
+    // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
+    // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2
+    // forces the path (tests, experiments).
+    bool use_glv = false;
+    if constexpr (GlvField<F>::value)
+        use_glv = ctx->glv_mode != 0 && !ctx->sort_atomic && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+                  (a.n <= (1u << 17) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
+    const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
+    if (use_glv) {
+        g.n = nv;
+        g.nbits = 128;
+        g.W = 8;
+    }
+    g.Wl = 0;
+    for (uint32_t w = 0; w < g.W; ++w)
+        if (w % g.nshards == g.shard) ++g.Wl;
+    ctx->geometry[0] = g.c;
+    ctx->geometry[1] = g.W;
+    ctx->geometry[2] = g.half;
+    ctx->geometry[3] = g.Wl;
+    ctx->geometry[4] = ctx->geometry[5] = 0;
+    sl->g = g;
+    if (g.Wl == 0) {
+        sl->trivial = true;
+        return 0;
+    }
+    const uint32_t NB = g.Wl * g.half;
+    const bool fast = (a.scalar_size % 4 == 0) && (((uintptr_t)d_scalars & 3) == 0);
+
+    HIPCHK(ctx, hipEventRecord(sl->ev[0], st));
+    // ---- Jacobian bases -> affine
+    if (jac) {
+        if (int rc = ensure(ctx, sl->d_affine, (size_t)a.n * ASZ)) return rc;
+        uint32_t lanes = (a.n + 7) / 8;
+        k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_affine.p);
+        d_bases = (const uint8_t*)sl->d_affine.p;
+    }
+    const uint8_t* d_xbeta = nullptr;
+    if constexpr (GlvField<F>::value) {
+        if (use_glv) {
+            if (int rc = ensure(ctx, sl->d_xbeta, (size_t)a.n * sizeof(F))) return rc;
+            k_glv_xbeta<F><<<(a.n + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_xbeta.p);
+            d_xbeta = (const uint8_t*)sl->d_xbeta.p;
+        }
+    }
+    HIPCHK(ctx, hipEventRecord(sl->ev[1], st));
+
+    const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
+    if (int rc = ensure(ctx, sl->d_count, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_cursor, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nv * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
+    uint32_t* count = (uint32_t*)sl->d_count.p;
+    uint32_t* offset = (uint32_t*)sl->d_offset.p;
+    uint32_t* cursor = (uint32_t*)sl->d_cursor.p;
+    uint32_t* order = (uint32_t*)sl->d_order.p;
+    uint32_t* bins = (uint32_t*)sl->d_bins.p;
+    uint32_t* tiles = (uint32_t*)sl->d_tiles.p;
+    uint32_t* sorted = (uint32_t*)sl->d_sorted.p;
+
+    const uint32_t nblk = (a.n + 255) / 256;
+    const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
+    // A lone call (nothing else in flight) is latency-bound at its end: the bucket reduction is ~40 dependent additions deep
+    // on one wave per SIMD.  Optionally (option "split") its windows are handled as two groups, the reduction of the first
+    // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
+    // reduction waves leave room for only one accumulation wave per SIMD, and two launches have two tails.  Kept for
+    // experiments, off by default; overlapping across calls (slots) is what pays.
+    bool others_pending = false;
+    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
+    const bool split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
+    const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
+    const uint32_t split = w_split * g.half;                                               // first bucket of the second group
+    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_KEYS * 4, st));
+    if (ctx->sort_atomic) {
+        // ---- 1. digits + histogram (global atomics)
+        HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
+        if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+        else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
+        // ---- 2. scan + order
+        k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
+        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
+        k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
+        k_order_scan<<<1, 1024, 0, st>>>(bins);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
+        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
+        // ---- 3. scatter
+        if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+        else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
+        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
+    } else {
+        // ---- 1. digit codes + coarse histogram
+        const uint32_t fine_bits = std::min(8u, g.c - 1);
+        const uint32_t cb = g.half >> fine_bits;                      // coarse bins per window (<= 128)
+        const uint32_t stile = (nv + SORT_TILE - 1) / SORT_TILE;
+        const size_t NM = (size_t)g.Wl * cb * stile;                   // count matrix entries (+1 for the total)
+        const uint32_t mtiles = (uint32_t)((NM + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        if (int rc = ensure(ctx, sl->d_dig, (size_t)g.Wl * nv * 2)) return rc;
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * 8)) return rc;
+        if (int rc = ensure(ctx, sl->d_M, (NM + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_Mscan, (NM + 1) * 4 * 2)) return rc;
+        if (int rc = ensure(ctx, sl->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
+        tiles = (uint32_t*)sl->d_tiles.p;
+        uint16_t* dig = (uint16_t*)sl->d_dig.p;
+        uint64_t* tmp = (uint64_t*)sl->d_tmp.p;
+        uint32_t* M = (uint32_t*)sl->d_M.p;
+        uint32_t* Mscan = (uint32_t*)sl->d_Mscan.p;
+        uint32_t* Mdummy = Mscan + (NM + 1);
+        const bool c16 = g.c == 16 && a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && g.W == 17 && (((uintptr_t)d_scalars & 15) == 0);
+        if (use_glv) k_digits_glv<<<nblk, 256, 0, st>>>(d_scalars, a.n, g, dig);
+        else if (c16) k_digits_c16<<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        else if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
+        HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
+        k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, M);
+        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
+        // ---- 2. scan of the count matrix
+        k_scan_tile_sums<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles);
+        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, mtiles);
+        k_scan_apply<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles, Mscan, Mdummy);
+        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
+        // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
+        k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, Mscan, tmp);
+        k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
+        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
+        k_order_scan<<<1, 1024, 0, st>>>(bins);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
+        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
+    }
+    // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation).
+    // A SMALL accumulation (fewer than two waves per SIMD: few owned windows of a sharded call, small n) cannot fill the
+    // chip by itself, so it goes to the slot's own stream instead and may overlap the accumulations of the other calls in flight.
+    const bool small_acc = NB < 2u * 1024u * 64u && !split_mode;
+    st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
+    HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
+    HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
+    // segment length: mean bucket population + 8 standard deviations of a Poisson bucket, at least 32: random inputs
+    // practically never exceed it (a handful of segments queued for the tail kernels costs a serial chain of `seg` additions
+    // on one lane, ~0.6 ms at seg = 32, which a 2x-the-mean rule paid at mean = 16).  Longer buckets -- adversarial scalars, or
+    // the few buckets of a narrow top window when the scalar width is not a multiple of c -- are cut into segments, which
+    // bounds the longest dependent chain of additions.
+    const uint32_t mean = (nv + g.half - 1) / g.half;
+    uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, mean + 8u * (uint32_t)std::ceil(std::sqrt((double)mean)) + 8u);
+    const size_t max_segs = (size_t)g.Wl * nv / seg + 1;
+    if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
+    if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
+    if (int rc = ensure(ctx, sl->d_segout, max_segs * BSZ)) return rc;
+    HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+    uint32_t tail_block = 256;
+    while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
+    uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
+    // G1 has two builds of the accumulation kernel (bucket_kernels.hpp): the chained one when the launch puts at least two waves
+    // on every SIMD, the two-chain one otherwise
+    auto accumulate = [&](const uint32_t* ord, uint32_t nbk) {
+        if constexpr (KernelField<F>::chained_variant) {
+            // few buckets with enough entries each (the windows of one rank of a sharded call): two lanes per bucket
+            if (!ctx->no_split2 && nbk < ctx->split2_nb && mean >= 16) {
+                launch_accumulate_split2<FK>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+                return;
+            }
+            if ((uint64_t)nbk >= 2u * 1024u * 64u) {
+                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+                return;
+            }
+        }
+        launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+    };
+    accumulate(order, split);
+    launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                               (uint8_t*)sl->d_segout.p, tail_block);
+    HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
+    if (split < NB) {
+        HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+        accumulate(order + split, NB - split);
+        launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                                   (uint8_t*)sl->d_segout.p, tail_block);
+    }
+    HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
+    // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
+    hipStream_t sb = sl->stream_b;
+    // buckets per lane: up to 8 (16 where a point takes two threads, so that the waves still fit one per SIMD) for a lone call (its reduction is on the critical path: short dependent chains, one wave on
+    // every SIMD); 32 when another call is already in flight: the reduction then hides behind that call's accumulation, and
+    // what counts is its SIMD time and its register footprint -- fewer, longer lanes issue fewer instructions in total
+    // (the double-and-add by the lane's first index is paid once per lane) and leave 3/4 of the SIMDs to the
+    // accumulation waves alone (n = 2^20, two calls in flight: 3.43 ms per call with L = 8, 3.09 ms with L = 32,
+    // 3.21 ms with L = 64 where the reduction outlasts the accumulation it hides behind)
+    struct Plan {
+        uint32_t L, lanes, rblock, wgs;
+    };
+    auto plan = [&](uint32_t nbuckets) {
+        Plan p;
+        p.L = others_pending ? std::min(32u, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
+                             : std::min(8u * lanes_per_point<FK>(), std::max(1u, (nbuckets * lanes_per_point<FK>() + 65535u) / 65536u));
+        // a power of two (the nearer one): a lane multiplies its run by its first index t*L with double-and-add, and the zero low
+        // bits of that index cost no additions (sharded calls: L = 10 -> 8 took 1.25 -> 1.17 ms per call at 4 ranks, 18 -> 16 1.62 -> 1.56 at 2)
+        {
+            uint32_t f = 1;
+            while (f * 2 <= p.L) f *= 2;
+            p.L = (2 * p.L >= 3 * f) ? 2 * f : f;
+        }
+        if (ctx->force_L) p.L = ctx->force_L;
+        p.lanes = (g.half + p.L - 1) / p.L;
+        p.rblock = std::min(256u, std::max(64u, p.lanes));
+        while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
+        p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
+        return p;
+    };
+    const Plan p0 = plan(split), p1 = plan(NB - split);
+    const uint32_t nparts0 = w_split * p0.wgs, nparts1 = (g.Wl - w_split) * p1.wgs, nparts = nparts0 + nparts1;
+    sl->part_off.assign(g.Wl, 0);
+    sl->part_cnt.assign(g.Wl, 0);
+    for (uint32_t wl = 0; wl < g.Wl; ++wl) {
+        sl->part_off[wl] = wl < w_split ? wl * p0.wgs : nparts0 + (wl - w_split) * p1.wgs;
+        sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
+    }
+    if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ)) return rc;
+    if (sl->h_partials_cap < (size_t)nparts * XSZ + 16) {
+        if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
+        sl->h_partials = nullptr;
+        sl->h_partials_cap = 0;
+        HIPCHK(ctx, hipHostMalloc(&sl->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
+        sl->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
+    }
+    uint8_t* partials = (uint8_t*)sl->d_partials.p;
+    HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
+    launch_bucket_reduce<FK>(sb, nparts0, p0.rblock, buckets, g.half, p0.L, p0.lanes, p0.wgs, partials, offset, count, 0, NB);
+    if (nparts1) {
+        hipStream_t sc = sl->stream_c;
+        HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
+        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * BSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ, offset,
+                                 count, split, NB);
+        HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
+        HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
+    }
+    HIPCHK(ctx, hipEventRecord(sl->ev[6], sb));
+    HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, sb));
+    // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
+    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
+    HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
+    HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
+    HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
+    const uint32_t wgs_per_window = p0.wgs;
+    sl->wgs_per_window = wgs_per_window;
+    sl->nparts = nparts;
+    sl->NB = NB;
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+template <class F>
+static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
+    using X = XYZZ<F>;
+    const size_t XSZ = sizeof(X);
+    for (float& t : ctx->timings) t = 0.f;
+    const Geom& g = sl->g;
+    ctx->geometry[0] = g.c;
+    ctx->geometry[1] = g.W;
+    ctx->geometry[2] = g.half;
+    ctx->geometry[3] = g.Wl;
+    ctx->geometry[4] = ctx->geometry[5] = 0;
+    if (sl->trivial) {
+        host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
+        return 0;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipEventSynchronize(sl->ev[7]));
+    const uint32_t nparts = sl->nparts;
+    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
+    {
+        uint64_t entries = (uint64_t)h_tail[0] + h_tail[1];
+        ctx->geometry[4] = (uint32_t)entries;
+        ctx->geometry[5] = (uint32_t)(entries >> 32);
+    }
+
+    // ---- 6. host combine: window sums, Horner over owned windows (top first), each weighted 2^(c*w)
+    auto t0 = std::chrono::steady_clock::now();
+    using HF = typename HostOf<F>::type;
+    using HX = XYZZ<HF>;
+    static_assert(sizeof(HX) == sizeof(X), "host twin has the same byte image");
+    const HX* parts = reinterpret_cast<const HX*>(sl->h_partials);
+    HX total = HX::inf();
+    int prev_w = -1;   // global index of the window most recently folded in
+    for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
+        int wglob = wl * (int)g.nshards + (int)g.shard;
+        if (prev_w >= 0)
+            for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = HX::dbl(total);
+        HX s = HX::inf();
+        for (uint32_t k = 0; k < sl->part_cnt[wl]; ++k) s = HX::add(s, parts[(size_t)sl->part_off[wl] + k]);
+        total = HX::add(total, s);
+        prev_w = wglob;
+    }
+    for (int k = 0; k < prev_w * (int)g.c; ++k) total = HX::dbl(total);
+    if (sl->raw_out) host_store_jacobian_raw(total, out);
+    else host_store_jacobian_normalised(total, out);
+    auto t1 = std::chrono::steady_clock::now();
+
+    float ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[7]); ctx->timings[0] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[1], sl->ev[2]); ctx->timings[1] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[2], sl->ev[3]); ctx->timings[2] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[3], sl->ev[4]); ctx->timings[3] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[9], sl->ev[5]); ctx->timings[4] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[5], sl->ev[6]); ctx->timings[5] = ms;
+    ctx->timings[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]); ctx->timings[7] = ms;
+    return 0;
+}
+
+static int check_args(msm_amd_ctx* ctx, const RunArgs& a) {
+    if (a.n && (!a.bases || !a.scalars)) {
+        msm_set_err(ctx, "null pointer");
+        return MSM_AMD_EINVAL;
+    }
+    if (a.scalar_size < 1 || a.scalar_size > 64) {
+        msm_set_err(ctx, "scalar_size must be in [1, 64]");
+        return MSM_AMD_EINVAL;
+    }
+    if (a.n > (1u << 27)) {   // (pair, window) positions are 32-bit: 17 windows x n must stay below 2^32
+        msm_set_err(ctx, "n must not exceed 2^27 per asynchronous call (the synchronous entry points slice larger inputs themselves)");
+        return MSM_AMD_EINVAL;
+    }
+    if (a.nshards == 0 || a.shard >= a.nshards) {
+        msm_set_err(ctx, "bad shard");
+        return MSM_AMD_EINVAL;
+    }
+    return 0;
+}
+
+// Queue one MSM on the next slot; the caller collects it with finish_ticket().
+static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint64_t* ticket, bool wait_for_slot = false) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (int rc = check_args(ctx, a)) return rc;
+    Slot* sl = nullptr;
+    for (;;) {
+        for (uint32_t k = 0; k < ctx->nslots; ++k) {   // tickets may be collected in any order: take any free slot
+            Slot* cand = &ctx->slots[(ctx->next_slot + k) % ctx->nslots];
+            if (!cand->pending) {
+                sl = cand;
+                break;
+            }
+        }
+        if (sl || !wait_for_slot) break;
+        // every slot is taken.  Slots held by synchronous calls of other threads will be collected by those threads: wait for one.
+        // If all of them hold asynchronous tickets, only the caller can free one -- waiting would never end.
+        bool some_sync = false;
+        for (uint32_t k = 0; k < ctx->nslots; ++k) some_sync |= ctx->slots[k].sync_owned;
+        if (!some_sync) break;
+        ctx->cv.wait(lk);
+    }
+    if (!sl) {
+        msm_set_err(ctx, "every slot of this context holds an uncollected call: wait for an older ticket first");
+        return MSM_AMD_EINVAL;
+    }
+    int rc;
+    if (curve == MSM_AMD_BLS12381 && group == 1) rc = submit_msm<Fp<Bls12381Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BLS12381 && group == 2) rc = submit_msm<Fp2<Bls12381Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BN128 && group == 1) rc = submit_msm<Fp<Bn254Fp>>(ctx, sl, a);
+    else if (curve == MSM_AMD_BN128 && group == 2) rc = submit_msm<Fp2<Bn254Fp>>(ctx, sl, a);
+    else {
+        msm_set_err(ctx, "unknown curve/group");
+        return MSM_AMD_EINVAL;
+    }
+    if (rc) {
+        // leave the streams clean so the context stays usable
+        (void)hipStreamSynchronize(ctx->stream_s);
+        if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(sl->stream_c);
+        (void)hipStreamSynchronize(sl->stream_b);
+        return rc;
+    }
+    sl->pending = true;
+    sl->sync_owned = wait_for_slot;
+    sl->ticket = ctx->next_ticket++;
+    *ticket = sl->ticket;
+    ctx->next_slot = ((uint32_t)(sl - ctx->slots) + 1u) % ctx->nslots;
+    return 0;
+}
+
+static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
+    if (!ctx || !out) return MSM_AMD_EINVAL;
+    Slot* found = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (Slot& sl : ctx->slots)
+            if (sl.pending && !sl.collecting && sl.ticket == ticket) {
+                found = &sl;
+                sl.collecting = true;
+                break;
+            }
+        if (!found) {
+            msm_set_err(ctx, "unknown or already collected ticket");
+            return MSM_AMD_EINVAL;
+        }
+    }
+    // wait for the GPU outside the lock (other threads may submit and collect meanwhile)
+    if (!found->trivial) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipEventSynchronize(found->ev[7]);
+    }
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        rc = found->finish(ctx, found, out);
+        found->pending = false;
+        found->collecting = false;
+        found->sync_owned = false;
+    }
+    ctx->cv.notify_all();
+    return rc;
+}
+
+static size_t elem_bytes(int curve, int group) { return (size_t)(curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group; }
+static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (!out) {
+        msm_set_err(ctx, "null pointer");
+        return MSM_AMD_EINVAL;
+    }
+    if (a.n <= ctx->max_slice) {
+        uint64_t t = 0;
+        if (int rc = submit(ctx, curve, group, a, &t, true)) return rc;
+        return finish_ticket(ctx, t, out);
+    }
+    // More points than one pass takes (the reference's external caller slices at 2^22 for its own reasons): the MSM is linear in the
+    // points, so run slice after slice -- two in flight -- and add the partial results on the host.  Works for host and for device
+    // pointers alike (plain address arithmetic); a shard call stays a shard call per slice.
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || !a.bases || !a.scalars) {
+        msm_set_err(ctx, "bad argument");
+        return MSM_AMD_EINVAL;
+    }
+    const size_t bstride = ((a.flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * elem_bytes(curve, group), jsz = 3 * elem_bytes(curve, group);
+    std::vector<uint8_t> parts;
+    uint64_t pending_ticket = 0;
+    bool have_pending = false;
+    int rc = 0;
+    for (uint64_t off = 0; off < a.n && rc == 0; off += ctx->max_slice) {
+        RunArgs s = a;
+        s.n = (uint32_t)std::min<uint64_t>(ctx->max_slice, a.n - off);
+        s.bases = (const uint8_t*)a.bases + off * bstride;
+        s.scalars = (const uint8_t*)a.scalars + off * a.scalar_size;
+        s.raw_out = true;   // un-normalised partial: one inversion at the very end
+        bool free_slot = false;
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu);
+            for (uint32_t k = 0; k < ctx->nslots; ++k) free_slot |= !ctx->slots[k].pending;
+        }
+        if (have_pending && !free_slot) {   // nothing free (a single slot, or the others are taken): collect our own slice first
+            parts.resize(parts.size() + jsz);
+            rc = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+            have_pending = false;
+            if (rc) break;
+        }
+        uint64_t t = 0;
+        rc = submit(ctx, curve, group, s, &t, true);
+        if (rc) break;
+        if (have_pending) {
+            parts.resize(parts.size() + jsz);
+            rc = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+        }
+        pending_ticket = t;
+        have_pending = true;
+    }
+    if (have_pending) {
+        parts.resize(parts.size() + jsz);
+        int rc2 = finish_ticket(ctx, pending_ticket, parts.data() + parts.size() - jsz);
+        if (!rc) rc = rc2;
+    }
+    if (rc) return rc;
+    return msm_amd_combine(curve, group, parts.data(), (uint32_t)(parts.size() / jsz), out);   // normalised (for a shard too: any representative will do)
+}
+
+template <class F>
+static int combine_t(const uint8_t* partials, uint32_t count, uint8_t* out) {
+    XYZZ<F> total = XYZZ<F>::inf();
+    for (uint32_t i = 0; i < count; ++i) total = XYZZ<F>::add(total, host_load_jacobian<F>(partials + (size_t)i * sizeof(Jacobian<F>)));
+    host_store_jacobian_normalised(total, out);
+    return 0;
+}
+template <class F, bool TO>
+static int f_conv(const uint8_t* in, uint32_t count, uint8_t* out) {
+    for (uint32_t i = 0; i < count; ++i) {
+        F x;
+        memcpy(&x, in + (size_t)i * sizeof(F), sizeof(F));
+        F r = TO ? F::to_mont(x) : F::from_mont(x);
+        memcpy(out + (size_t)i * sizeof(F), &r, sizeof(F));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+// One wave that spins for `ticks` of the 100-MHz wall clock: the probe of the stream calibration below and of
+// msm_amd_debug_stream_sharing.
+__global__ void k_spin(uint64_t ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// true when kernels on a and b serialise, i.e. the two streams were mapped onto the same hardware queue
+static bool streams_serialise(hipStream_t a, hipStream_t b) {
+    const uint64_t ticks = 15000;   // 0.15 ms each: ~0.17 ms together on different queues, ~0.32 ms on a shared one
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        auto t0 = std::chrono::steady_clock::now();
+        k_spin<<<1, 64, 0, a>>>(ticks);
+        k_spin<<<1, 64, 0, b>>>(ticks);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return false;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us < 245.0) return false;   // concurrent (a slow verdict is taken twice before it is believed)
+    }
+    return true;
+}
+
+// HIP maps the streams of a process onto a few hardware queues (four by default), by creation order and by what the process created
+// before -- and streams on one queue serialise.  Which of the engine's streams share a queue decides its throughput (n = 2^20, two
+// calls in flight: 2.7-2.9 ms per call when A, S, B0 and B1 sit on four queues; 3.1-3.3 when A shares with S; 3.4-3.5 when A shares
+// with B1; 3.6-3.75 when S shares with a B: profiles/r01_stream_queue_layouts.log).  So the context does not trust the creation
+// order: it finds the queue classes of the streams it created (probe above, ~10 ms) and deals them out so that the streams that work
+// side by side sit on different queues: A, S, B0, B1 on four classes; B2 with A and B3 with S (when four sharded calls are in flight
+// A and S idle: their accumulations run on the B streams, their sorts on S2).  MSM_AMD_NO_CALIBRATE=1 keeps the creation order.
+static void calibrate_streams(msm_amd_ctx* ctx) {
+    if (getenv("MSM_AMD_NO_CALIBRATE")) return;
+    std::vector<hipStream_t> all = {ctx->stream, ctx->stream_s};
+    for (Slot& sl : ctx->slots) {
+        all.push_back(sl.stream_b);
+        all.push_back(sl.stream_c);
+    }
+    k_spin<<<1, 64, 0, all[0]>>>(100);   // loads the code object before anything is timed
+    if (hipDeviceSynchronize() != hipSuccess) return;
+    std::vector<std::vector<hipStream_t>> cls;
+    for (hipStream_t st : all) {
+        bool placed = false;
+        for (auto& c : cls)
+            if (streams_serialise(c[0], st)) {
+                c.push_back(st);
+                placed = true;
+                break;
+            }
+        if (!placed) cls.push_back({st});
+    }
+    (void)hipGetLastError();
+    if (cls.size() < 2) return;
+    const size_t nc = cls.size();
+    std::vector<hipStream_t> rest;
+    auto take = [&](size_t c) -> hipStream_t {
+        for (size_t k = 0; k < nc; ++k) {   // the wanted class, else the next one that still has a stream
+            auto& v = cls[(c + k) % nc];
+            if (!v.empty()) {
+                hipStream_t st = v.back();
+                v.pop_back();
+                return st;
+            }
+        }
+        return nullptr;
+    };
+    ctx->stream = take(0);
+    ctx->stream_s = take(1);
+    const size_t nslots = sizeof(ctx->slots) / sizeof(ctx->slots[0]);
+    for (size_t k = 0; k < nslots; ++k) ctx->slots[k].stream_b = take((2 + k) % nc);
+    for (size_t k = 0; k < nslots; ++k) ctx->slots[k].stream_c = take((2 + k) % nc);
+}
+
+int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
+    if (!out_ctx) return MSM_AMD_EINVAL;
+    *out_ctx = nullptr;
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0 || device_id < 0 || device_id >= cnt) return MSM_AMD_EHIP;
+    msm_amd_ctx* ctx = new (std::nothrow) msm_amd_ctx();
+    if (!ctx) return MSM_AMD_ENOMEM;
+    ctx->device = device_id;
+    if (const char* e = getenv("MSM_AMD_REDUCE_L")) ctx->force_L = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return MSM_AMD_EHIP;
+    }
+    for (Slot& sl : ctx->slots) {
+        if (hipStreamCreateWithFlags(&sl.stream_b, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&sl.stream_c, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&sl.ev_c) != hipSuccess) {
+            delete ctx;
+            return MSM_AMD_EHIP;
+        }
+        for (auto& e : sl.ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                delete ctx;
+                return MSM_AMD_EHIP;
+            }
+    }
+    calibrate_streams(ctx);
+    *out_ctx = ctx;
+    return MSM_AMD_OK;
+}
+
+void msm_amd_destroy(msm_amd_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
+    if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (Slot& sl : ctx->slots) {
+        if (sl.stream_b) {
+            (void)hipStreamSynchronize(sl.stream_b);
+            (void)hipStreamDestroy(sl.stream_b);
+        }
+        if (sl.stream_c) {
+            (void)hipStreamSynchronize(sl.stream_c);
+            (void)hipStreamDestroy(sl.stream_c);
+        }
+        if (sl.ev_c) (void)hipEventDestroy(sl.ev_c);
+        for (DevBuf* b : sl.bufs)
+            if (b->p) (void)hipFree(b->p);
+        if (sl.h_partials) (void)hipHostFree(sl.h_partials);
+        for (auto& e : sl.ev)
+            if (e) (void)hipEventDestroy(e);
+    }
+    if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
+    if (ctx->stream_s2) (void)hipStreamDestroy(ctx->stream_s2);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* msm_amd_last_error(const msm_amd_ctx* ctx) {
+    if (!ctx) return "null context";
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
+
+// Diagnostic: which of the context's streams serialise with each other, i.e. were mapped onto the same hardware queue (DESIGN.md
+// section 7).  Streams 0..10 = A, S, B0, C0, B1, C1, B2, C2, B3, C3 and the process's null stream.  A one-wave kernel that spins for ~0.3 ms is launched on two
+// streams at once: together they take ~0.3 ms on different queues, ~0.6 ms on a shared one.  out[i*11+j] = 1 when i and j serialise.
+int msm_amd_debug_stream_sharing(msm_amd_ctx* ctx, uint8_t* out) {
+    if (!ctx || !out) return MSM_AMD_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st[11] = {ctx->stream, ctx->stream_s};
+    st[10] = nullptr;
+    for (int k = 0; k < 4; ++k) {
+        st[2 + 2 * k] = ctx->slots[k].stream_b;
+        st[3 + 2 * k] = ctx->slots[k].stream_c;
+    }
+    const uint64_t ticks = 30000;   // wall_clock64 counts at 100 MHz: 0.3 ms
+    k_spin<<<1, 64, 0, st[0]>>>(1000);
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (int i = 0; i < 11; ++i)
+        for (int j = 0; j < 11; ++j) out[i * 11 + j] = i == j;
+    for (int i = 0; i < 11; ++i)
+        for (int j = i + 1; j < 11; ++j) {
+            auto t0 = std::chrono::steady_clock::now();
+            k_spin<<<1, 64, 0, st[i]>>>(ticks);
+            k_spin<<<1, 64, 0, st[j]>>>(ticks);
+            HIPCHK(ctx, hipStreamSynchronize(st[i]));
+            HIPCHK(ctx, hipStreamSynchronize(st[j]));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            out[i * 11 + j] = out[j * 11 + i] = us > 470.0;
+        }
+    return MSM_AMD_OK;
+}
+
+int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
+    if (!ctx || !name) return MSM_AMD_EINVAL;
+    if (!strcmp(name, "window_bits")) return msm_amd_set_window_bits(ctx, value);
+    if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
+    if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
+    if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
+    if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
+    if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
+    if (!strcmp(name, "split2")) { ctx->no_split2 = value == 0; return 0; }
+    if (!strcmp(name, "split2_nb")) { ctx->split2_nb = value; return 0; }
+    if (!strcmp(name, "slice")) {
+        if (value < 1 || value > (1u << 27)) { msm_set_err(ctx, "slice must be in [1, 2^27]"); return MSM_AMD_EINVAL; }
+        ctx->max_slice = value;
+        return 0;
+    }
+    if (!strcmp(name, "slots")) {
+        if (value < 1 || value > msm_amd_ctx::MAX_SLOTS) { msm_set_err(ctx, "slots must be in [1, 8]"); return MSM_AMD_EINVAL; }
+        for (Slot& sl : ctx->slots)
+            if (sl.pending) { msm_set_err(ctx, "cannot change the slot count with calls in flight"); return MSM_AMD_EINVAL; }
+        ctx->nslots = value;
+        ctx->next_slot = 0;
+        return 0;
+    }
+    msm_set_err(ctx, "unknown option");
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
+    if (!ctx || c > 16) return MSM_AMD_EINVAL;
+    ctx->force_c = c;
+    return 0;
+}
+
+int msm_amd_multiexp(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
+                     uint32_t n, uint8_t* out) {
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
+    return dispatch(ctx, curve, group, a, out);
+}
+
+int msm_amd_multiexp_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
+                           uint32_t n, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false};
+    return submit(ctx, curve, group, a, ticket);
+}
+
+int msm_amd_multiexp_shard_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                                 uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, shard, nshards, true};
+    return submit(ctx, curve, group, a, ticket);
+}
+
+int msm_amd_wait(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) { return finish_ticket(ctx, ticket, out); }
+
+int msm_amd_multiexp_chunk(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                           uint32_t scalar_size, uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (chunk_size < 1 || chunk_size > 25) {   // build_multiexp.js:25-94 is exact for chunkSize <= 25
+        msm_set_err(ctx, "chunk_size must be in [1, 25]");
+        return MSM_AMD_EINVAL;
+    }
+    uint32_t total = scalar_size * 8;
+    uint32_t nbits = start_bit >= total ? 0u : std::min(chunk_size, total - start_bit);
+    RunArgs a{bases, scalars, scalar_size, n, flags, start_bit, nbits, 0, 1, false};
+    return dispatch(ctx, curve, group, a, out);
+}
+
+int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars,
+                           uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards, uint8_t* out_partial) {
+    RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, shard, nshards, true};
+    return dispatch(ctx, curve, group, a, out_partial);
+}
+
+#define BY_FIELD(curve, group, CALL)                                                         \
+    do {                                                                                     \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 1) { using F = FpH<Bls12381Fp>; CALL; }        \
+        if ((curve) == MSM_AMD_BLS12381 && (group) == 2) { using F = Fp2T<FpH<Bls12381Fp>>; CALL; }  \
+        if ((curve) == MSM_AMD_BN128 && (group) == 1) { using F = FpH<Bn254Fp>; CALL; }              \
+        if ((curve) == MSM_AMD_BN128 && (group) == 2) { using F = Fp2T<FpH<Bn254Fp>>; CALL; }        \
+    } while (0)
+
+int msm_amd_combine(int curve, int group, const uint8_t* partials, uint32_t count, uint8_t* out) {
+    if (!partials || !out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, return combine_t<F>(partials, count, out));
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_normalize(int curve, int group, const uint8_t* jac_in, uint8_t* jac_out) {
+    if (!jac_in || !jac_out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        host_store_jacobian_normalised(host_load_jacobian<F>(jac_in), jac_out);
+        return 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_to_affine(int curve, int group, const uint8_t* jac_in, uint8_t* aff_out) {
+    if (!jac_in || !aff_out) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        Affine<F> a = XYZZ<F>::to_affine(host_load_jacobian<F>(jac_in));
+        memcpy(aff_out, &a, sizeof(a));
+        return 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_eq(int curve, int group, const uint8_t* jac_a, const uint8_t* jac_b) {
+    if (!jac_a || !jac_b) return MSM_AMD_EINVAL;
+    BY_FIELD(curve, group, {
+        XYZZ<F> d = XYZZ<F>::add(host_load_jacobian<F>(jac_a), XYZZ<F>::neg(host_load_jacobian<F>(jac_b)));
+        return d.is_inf() ? 1 : 0;
+    });
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_f_to_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
+    if (!in || !out) return MSM_AMD_EINVAL;
+    if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, true>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, true>(in, count, out);
+    return MSM_AMD_EINVAL;
+}
+int msm_amd_f_from_montgomery(int curve, const uint8_t* in, uint32_t count, uint8_t* out) {
+    if (!in || !out) return MSM_AMD_EINVAL;
+    if (curve == MSM_AMD_BLS12381) return f_conv<FpH<Bls12381Fp>, false>(in, count, out);
+    if (curve == MSM_AMD_BN128) return f_conv<FpH<Bn254Fp>, false>(in, count, out);
+    return MSM_AMD_EINVAL;
+}
+
+int msm_amd_dev_alloc(msm_amd_ctx* ctx, size_t bytes, void** dev_ptr) {
+    if (!ctx || !dev_ptr) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return 0;
+}
+int msm_amd_dev_free(msm_amd_ctx* ctx, void* dev_ptr) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(dev_ptr));
+    return 0;
+}
+int msm_amd_h2d(msm_amd_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int msm_amd_d2h(msm_amd_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int msm_amd_get_timings(const msm_amd_ctx* ctx, float* ms, int capacity) {
+    if (!ctx || !ms) return MSM_AMD_EINVAL;
+    int k = std::min(capacity, 8);
+    for (int i = 0; i < k; ++i) ms[i] = ctx->timings[i];
+    return k;
+}
+int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out6) {
+    if (!ctx || !out6) return MSM_AMD_EINVAL;
+    for (int i = 0; i < 6; ++i) out6[i] = ctx->geometry[i];
+    return 0;
+}
+
+#define MSM_AMD_DEF(curve, g, CID, GID)                                                                                                    \
+    int msm_##curve##_##g##_multiexp(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size, uint32_t n,     \
+                                     uint8_t* out) {                                                                                       \
+        return msm_amd_multiexp(ctx, CID, GID, MSM_AMD_BASES_JACOBIAN, bases, scalars, scalar_size, n, out);                               \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexpAffine(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,           \
+                                           uint32_t n, uint8_t* out) {                                                                     \
+        return msm_amd_multiexp(ctx, CID, GID, 0, bases, scalars, scalar_size, n, out);                                                    \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexp_chunk(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,           \
+                                           uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {                            \
+        return msm_amd_multiexp_chunk(ctx, CID, GID, MSM_AMD_BASES_JACOBIAN, bases, scalars, scalar_size, n, start_bit, chunk_size, out);  \
+    }                                                                                                                                      \
+    int msm_##curve##_##g##_multiexpAffine_chunk(msm_amd_ctx* ctx, const uint8_t* bases, const uint8_t* scalars, uint32_t scalar_size,     \
+                                                 uint32_t n, uint32_t start_bit, uint32_t chunk_size, uint8_t* out) {                      \
+        return msm_amd_multiexp_chunk(ctx, CID, GID, 0, bases, scalars, scalar_size, n, start_bit, chunk_size, out);                       \
+    }
+MSM_AMD_DEF(bls12381, g1m, MSM_AMD_BLS12381, 1)
+MSM_AMD_DEF(bls12381, g2m, MSM_AMD_BLS12381, 2)
+MSM_AMD_DEF(bn128, g1m, MSM_AMD_BN128, 1)
+MSM_AMD_DEF(bn128, g2m, MSM_AMD_BN128, 2)
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+// engine_ctx.hpp -- the host-side state behind msm_amd_ctx (slots, streams, scratch buffers), error reporting and the small host
+// helpers that every translation unit of the library shares (engine.hip, conv_kernels.hip, fft_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/msm_amd.h"
+#include "engine_common.hpp"
+#include "field_host.hpp"
+#include "glv.hpp"
+
+namespace msm {
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace msm
+
+using namespace msm;
+
+// One in-flight MSM: its scratch buffers, events and what the host needs to finish it.  A context owns
+// two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
+// the sort + accumulation of the next call (throughput-bound, stream A).
+struct Slot {
+    DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
+    DevBuf d_xbeta;   // GLV path: beta * x of every base
+    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
+    void* h_partials = nullptr;   // pinned
+    size_t h_partials_cap = 0;
+    hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts
+    hipStream_t stream_b = nullptr;   // B: this slot's bucket reduction + partials to host
+    hipStream_t stream_c = nullptr;   // C: reduction of the second window group when a lone call is split in two
+    hipEvent_t ev_c = nullptr;        // second group's reduction done
+    std::vector<uint32_t> part_off, part_cnt;   // per owned window: first partial, number of partials
+    bool pending = false;
+    bool collecting = false;      // a thread is waiting for / combining this call
+    bool sync_owned = false;      // submitted by a synchronous entry point: its own thread will collect it
+    bool trivial = false;         // n == 0 / empty bit range / no owned window: the result is infinity, no GPU work queued
+    uint64_t ticket = 0;
+    Geom g{};
+    uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
+    bool raw_out = false;
+    int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
+    DevBuf* bufs[21] = {&d_xbeta, &d_dig, &d_tmp, &d_M, &d_Mscan, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+                        &d_affine, &d_count, &d_offset, &d_cursor, &d_order, &d_bins, &d_tiles, &d_sorted, &d_buckets, &d_partials};
+};
+
+struct msm_amd_ctx {
+    int device = 0;
+    // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are
+    // serialised by `mu`; WAITING for the GPU happens outside it, so calls issued from different threads -- e.g. the libuv
+    // workers behind two unresolved JS promises -- overlap on the GPU like explicitly pipelined ones.  A synchronous call that
+    // finds every slot taken sleeps on `cv` until one is collected.
+    std::mutex mu;
+    std::condition_variable cv;
+    hipStream_t stream = nullptr;     // A: bucket accumulation (the ALU-bound stage), in call order
+    hipStream_t stream_s = nullptr;   // S: transfers + bucket sort of the NEXT call, under the current call's accumulation
+    hipStream_t stream_s2 = nullptr;  // S2: the same for calls whose accumulation is small (few owned windows of a sharded call, small n)
+    static constexpr uint32_t MAX_SLOTS = 8;
+    Slot slots[MAX_SLOTS];
+    uint32_t nslots = 2;              // calls that may be in flight ("slots" option, 1..8)
+    uint32_t next_slot = 0;
+    uint64_t next_ticket = 1;
+    std::string err;
+    uint32_t force_c = 0;
+    uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
+    uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    int no_split2 = 0;      // option "split2" = 0 switches the two-lanes-per-bucket accumulation of small launches off
+    uint32_t split2_nb = 2u * 1024u * 64u;   // option "split2_nb": launches with fewer buckets than this use it (default: two waves per SIMD)
+    uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
+    int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
+    int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
+    int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
+    float timings[8] = {};
+    uint32_t geometry[6] = {};
+};
+
+// Error text of a context.  Written by whichever thread fails (several may use one context: the libuv workers of the Node addon),
+// so it is guarded by its own small lock, and msm_amd_last_error hands out a per-thread copy.
+void msm_set_err(msm_amd_ctx* ctx, const std::string& msg);
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            msm_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e_));                             \
+            return MSM_AMD_EHIP;                                                                               \
+        }                                                                                                      \
+    } while (0)
+
+inline int ensure(msm_amd_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (b.cap >= bytes && b.p) return 0;
+    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+template <class F>
+static void host_store_jacobian_normalised(const XYZZ<F>& r, uint8_t* out) {
+    Affine<F> a = XYZZ<F>::to_affine(r);
+    F one = F::one(), zero = F::zero();
+    if (r.is_inf()) {
+        memcpy(out, &zero, sizeof(F));
+        memcpy(out + sizeof(F), &one, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &zero, sizeof(F));
+    } else {
+        memcpy(out, &a.x, sizeof(F));
+        memcpy(out + sizeof(F), &a.y, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &one, sizeof(F));
+    }
+}
+// un-normalised Jacobian image of an XYZZ point: (X*ZZ*ZZZ^2.. ) -- choose Z = ZZZ*ZZ? we use the
+// identity x = X/ZZ = (X*ZZ)/ZZ^2... simplest exact map: Z = ZZ * ZZZ, X' = X * ZZ * ZZZ^2, Y' = Y * ZZ^3 * ZZZ^2.
+// (Z^2 = ZZ^2 ZZZ^2 => X'/Z^2 = X/ZZ ; Z^3 = ZZ^3 ZZZ^3 => Y'/Z^3 = Y/ZZZ.)
+template <class F>
+static void host_store_jacobian_raw(const XYZZ<F>& r, uint8_t* out) {
+    F one = F::one(), zero = F::zero();
+    if (r.is_inf()) {
+        memcpy(out, &zero, sizeof(F));
+        memcpy(out + sizeof(F), &one, sizeof(F));
+        memcpy(out + 2 * sizeof(F), &zero, sizeof(F));
+        return;
+    }
+    F zzz2 = F::sqr(r.zzz);
+    F x = F::mul(F::mul(r.x, r.zz), zzz2);
+    F zz3 = F::mul(F::sqr(r.zz), r.zz);
+    F y = F::mul(F::mul(r.y, zz3), zzz2);
+    F z = F::mul(r.zz, r.zzz);
+    memcpy(out, &x, sizeof(F));
+    memcpy(out + sizeof(F), &y, sizeof(F));
+    memcpy(out + 2 * sizeof(F), &z, sizeof(F));
+}
+template <class F>
+static XYZZ<F> host_load_jacobian(const uint8_t* in) {
+    Jacobian<F> j;
+    memcpy(&j, in, sizeof(j));
+    return XYZZ<F>::from_jacobian(j);
+}
+
+template <class P>
+static Fp<P> fp_from(const uint32_t* limbs) {
+    Fp<P> r;
+    for (int i = 0; i < P::N; ++i) r.v[i] = limbs[i];
+    return r;
+}
+
+// k_jacobian_to_affine: g?m_batchToAffine and the Jacobian-bases entry of the MSM share it
+namespace msm {
+// ------------------------------------------------------------------------------------------
+// Jacobian bases -> affine (g?m_multiexp entry point): Montgomery's trick, 8 points per lane
+// (build_curve_jacobian_a0.js:1040-1125 batchToAffine does the same thing sequentially).
+// ------------------------------------------------------------------------------------------
+template <class F>
+__global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __restrict__ jac, uint32_t n, uint8_t* __restrict__ aff) {
+    constexpr int K = 8;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t first = t * K;
+    if (first >= n) return;
+    F pref[K];
+    F acc = F::one();
+    for (int k = 0; k < K; ++k) {
+        uint32_t i = first + k;
+        pref[k] = acc;
+        if (i < n) {
+            F z = load16<F>(jac + (size_t)i * 3 * sizeof(F) + 2 * sizeof(F));
+            if (!z.is_zero()) acc = F::mul(acc, z);
+        }
+    }
+    F inv = F::inv(acc);
+    for (int k = K - 1; k >= 0; --k) {
+        uint32_t i = first + k;
+        if (i >= n) continue;
+        Jacobian<F> p = load16<Jacobian<F>>(jac + (size_t)i * sizeof(Jacobian<F>));
+        Affine<F> a;
+        if (p.z.is_zero()) {
+            a = {F::zero(), F::zero()};
+        } else {
+            F zi = F::mul(inv, pref[k]);
+            inv = F::mul(inv, p.z);
+            F zi2 = F::sqr(zi);
+            a.x = F::mul(p.x, zi2);
+            a.y = F::mul(p.y, F::mul(zi2, zi));
+        }
+        store16(aff + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
+    }
+}
+
+}  // namespace msm
