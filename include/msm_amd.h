@@ -51,8 +51,12 @@ enum {
     MSM_AMD_BASES_JACOBIAN = 1, /* bases are X||Y||Z (g?m_multiexp); default affine x||y (g?m_multiexpAffine) */
     MSM_AMD_DEVICE_PTRS = 2,    /* bases and scalars already live in this context's GPU memory              */
     MSM_AMD_FFT_INVERSE = 8,    /* msm_amd_fft: the inverse transform (g?m_ifft / frm_ifft)                                */
-    MSM_AMD_DEVICE_BASES = 4    /* only the bases are resident on the GPU (msm_amd_dev_alloc + msm_amd_h2d once: the fixed
+    MSM_AMD_DEVICE_BASES = 4,   /* only the bases are resident on the GPU (msm_amd_dev_alloc + msm_amd_h2d once: the fixed
                                    SRS of a prover); the scalars are a host buffer copied over PCIe by every call    */
+    MSM_AMD_BASES_IN_SUBGROUP = 16 /* the caller vouches that every base lies in the order-r subgroup (what
+                                   msm_amd_batch_in_group_affine checks; true of any SRS).  Allows the engine's GLV schedule
+                                   (BLS12-381 G1, 1024 <= n <= 2^17), which reduces scalars mod r and uses the endomorphism: correct in
+                                   the subgroup only.  Without the flag the result is the reference's for ANY points of the curve. */
 };
 
 /* error codes */
@@ -73,7 +77,8 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
  * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight, 1..8),
  * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default),
- * "glv" (0 never | 1 where it pays (default) | 2 whenever it applies: the GLV schedule of BLS12-381 G1),
+ * "glv" (0 never | 1 (default) where it pays AND the call carries MSM_AMD_BASES_IN_SUBGROUP | 2 whenever it applies, the option itself
+ * being the caller's word that the bases lie in the order-r subgroup: the GLV schedule of BLS12-381 G1),
  * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice),
  * "split2" (0 = never give a bucket two lanes; default 1: G1 launches with few buckets do), "split2_nb" (bucket count below
  * which they do, default 131072 = two waves per SIMD). */

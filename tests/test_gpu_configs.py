@@ -1,0 +1,229 @@
+"""GPU tests added in round 2 (run with -m gpu on the MI355X box):
+  * the BASELINE configurations at their stated sizes (config 3: BLS12-381 G1 n = 2^26; config 5: BN254 G1 n = 2^24; config 4:
+    BLS12-381 G2 n = 2^20) through size-independent properties + an oracle spot slice -- they cross thresholds smaller cases do
+    not (32-bit positions, multi-GiB scratch, wide windows, deep buckets);
+  * bases outside the order-r subgroup (the reference's multiexp is exact for any point of the curve);
+  * the guard on 32-bit (pair, window) positions;
+  * `bench.py --gpus 2` end to end (ranks started by bench.py itself; gloo on a one-GPU box, RCCL when two GPUs are present);
+  * two ranks on two GPUs exchanging their window partials over RCCL (skipped on a one-GPU box)."""
+import ctypes
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import msm_amd
+    e = msm_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(oracle_lib):
+    return oracle_lib
+
+
+def _call(eng, C, group, bases_ptr, scalars_ptr, n, flags=0):
+    """msm_amd_multiexp on raw device addresses (slices of one resident buffer: plain pointer arithmetic)"""
+    import msm_amd
+    out = ctypes.create_string_buffer(C.jacobian_bytes(group))
+    eng._chk(eng.L.msm_amd_multiexp(eng.ctx, C.cid, group, msm_amd.FLAG_DEVICE | flags, bases_ptr, scalars_ptr, 32, n, out))
+    return out.raw
+
+
+@pytest.mark.parametrize("curve,group,logn", [("bls12381", 1, 26), ("bn128", 1, 24), ("bls12381", 2, 20)])
+def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
+    """BASELINE.json configs 3, 5 and 4 at their stated sizes on one GPU: the eight window shards of the multi-GPU decomposition add
+    up to the full result; two point slices add up to it (MSM is linear in the points); the scalar halves k = lo + 2^128 hi do;
+    a 2^11 slice of the very same resident inputs equals the oracle."""
+    import torch
+    import msm_amd
+    n = 1 << logn
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    asz = C.affine_bytes(group)
+    pts = C.gen_points(group, 0xC0F16 + logn, n)
+    # scalars on the GPU (2 GiB at n = 2^26: never staged through numpy), 255 significant bits
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234 + logn)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    sc[:, 31] &= 0x7F
+    torch.cuda.synchronize()
+    sp = sc.data_ptr()
+    try:
+        full = _call(eng, C, group, pts.ptr, sp, n)
+        geom = eng.geometry()
+        assert geom["entries"] > n * 14                        # every window of every pair was scattered
+        # (1) the multi-GPU decomposition on one GPU
+        parts = b"".join(C.multiexp_shard(group, pts, sc, 32, n, r, 8) for r in range(8))
+        assert msm_amd.combine(curve, group, parts) == full
+        # (2) point slices: uneven cut, so the two halves see different n (and possibly different window sizes)
+        cut = (n // 3) | 1
+        lo = _call(eng, C, group, pts.ptr, sp, cut)
+        hi = _call(eng, C, group, pts.ptr + cut * asz, sp + cut * 32, n - cut)
+        assert msm_amd.combine(curve, group, lo + hi) == full
+        # (3) oracle spot slice of the same resident inputs
+        m = 2048
+        h_pts = pts.download(m * asz)
+        h_sc = sc[:m].cpu().numpy().tobytes()
+        exp = O.normalize(O.multiexp_affine(h_pts, h_sc, 32, m))
+        assert _call(eng, C, group, pts.ptr, sp, m) == exp
+        # (4) the _chunk entry point at full size: bits [0, 128) and [128, 256) through 25-bit chunks would take 11 calls; take the
+        #     two halves of the scalar instead: sum_i (k_i mod 2^128) P_i + 2^128 sum_i (k_i >> 128) P_i == full
+        lo128 = sc.clone()
+        lo128[:, 16:] = 0
+        hi128 = torch.zeros_like(sc)
+        hi128[:, :16] = sc[:, 16:]
+        torch.cuda.synchronize()
+        a = _call(eng, C, group, pts.ptr, lo128.data_ptr(), n)
+        b = _call(eng, C, group, pts.ptr, hi128.data_ptr(), n)
+        acc = b
+        for _ in range(128):
+            acc = O.double(acc)
+        assert O.normalize(O.add(acc, a)) == full
+    finally:
+        pts.free()
+        del sc
+        torch.cuda.empty_cache()
+
+
+def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
+    """The reference's g1m_multiexpAffine is integer arithmetic on curve points: exact for points outside the order-r subgroup too.
+    The engine's GLV schedule (k mod r, endomorphism) is not -- so it only runs for callers that pass MSM_AMD_BASES_IN_SUBGROUP.
+    n = 2048 sits in the range where the GLV schedule is the default for flagged calls."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 2048
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    with open(os.path.join(gu.GOLDEN, "golden_ingroup.json")) as f:
+        cases = [c for c in json.load(f)["cases"] if c["curve"] == curve and c["group"] == group]
+    outside = []
+    for c in cases:
+        aff = bytes.fromhex(c["affine_in"])
+        for i, (ing, inc) in enumerate(zip(c["inGroupAffine"], c["inCurveAffine"])):
+            if inc and not ing:
+                outside.append(aff[96 * i:96 * (i + 1)])
+    assert outside, "the fixture holds on-curve points outside the subgroup"
+    bases, scalars = gu.random_case(curve, group, "gpu:cofactor", n)
+    bases = bytearray(bases)
+    for i in range(0, n, 3):                                   # every third base is a cofactor point
+        bases[96 * i:96 * (i + 1)] = outside[(i // 3) % len(outside)]
+    bases = bytes(bases)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp               # default: no assumption about the bases
+    assert eng.geometry()["windows"] == 17
+    # flagged calls take the GLV schedule; with bases that really are in the subgroup it gives the reference's bytes
+    good, gs = gu.random_case(curve, group, "gpu:cofactor:good", n)
+    expg = O.normalize(O.multiexp_affine(good, gs, 32, n))
+    assert C.g1m_multiexpAffine(good, gs, 32, n, in_subgroup=True) == expg
+    assert eng.geometry()["windows"] == 8
+    assert C.g1m_multiexpAffine(good, gs, 32, n) == expg
+
+
+def test_entries_of_one_pass_must_fit_32_bits(eng):
+    """windows x points >= 2^32 would wrap the 32-bit positions of the sort: refused, not computed wrongly.  One-bit windows over
+    256-bit scalars are 257 windows; 2^24 points x 257 > 2^32.  (Buffers are uninitialised: the call is refused before any kernel.)"""
+    import msm_amd
+    n = 1 << 24
+    C = eng.curve("bn128")
+    b, s = eng.alloc(n * 64), eng.alloc(n * 32)
+    try:
+        eng.set_window_bits(1)
+        with pytest.raises(msm_amd.MsmAmdError, match="2\\^32"):
+            C.multiexp_async(1, b, s, 32, n)
+        eng.set_window_bits(0)
+        # the context stays usable
+        bases, scalars = gu.random_case("bn128", 1, "gpu:guard", 64)
+        assert len(C.g1m_multiexpAffine(bases, scalars, 32, 64)) == 96
+    finally:
+        eng.set_window_bits(0)
+        b.free()
+        s.free()
+
+
+def test_bench_gpus_2_reports_two_ranks():
+    """`python bench.py --gpus 2` as the driver types it (no launcher around it): bench.py starts the two ranks itself.  With two GPUs
+    the exchange is RCCL; on a one-GPU box the same flow is rehearsed with gloo, both ranks on the one GPU."""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if torch.cuda.device_count() < 2:
+        env["MSM_BENCH_BACKEND"] = "gloo"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--logn", "16"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
+    assert "sharded over 2" in line["config"]["parallelism"]
+
+
+def _rccl_rank(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "zprize-wasm-msm_amd", "python")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    import torch
+    import torch.distributed as dist
+    import msm_amd
+    from msm_amd import dist as mdist
+    from oracle import oracle as orcm
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+    eng = msm_amd.Engine(rank)
+    try:
+        curve, group, n = "bls12381", 1, 5000
+        C = eng.curve(curve)
+        bases, scalars = gu.random_case(curve, group, "gpu:rccl2", n)
+        d_b = eng.alloc(len(bases)).upload(bases)
+        d_s = eng.alloc(len(scalars)).upload(scalars)
+        # this rank's windows on ITS OWN GPU, two calls in flight, partials exchanged over RCCL/xGMI
+        t1 = C.multiexp_shard_async(group, d_b, d_s, 32, n, rank, world)
+        t2 = C.multiexp_shard_async(group, d_b, d_s, 32, n, rank, world)
+        xch = mdist.PartialExchange(curve, group, device=dev)
+        h1, h2 = xch.submit(t1.wait()), xch.submit(t2.wait())
+        r1, r2 = xch.result(h1), xch.result(h2)
+        r3 = mdist.multiexp_sharded(C, group, d_b, d_s, 32, n, device=dev)
+        ok = r1 == r2 == r3
+        if rank == 0:
+            orcm.build()
+            O = orcm.Oracle(curve, group)
+            ok = ok and r1 == O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        q.put((rank, ok, r1.hex()[:16]))
+    finally:
+        eng.close()
+        dist.destroy_process_group()
+
+
+def test_two_ranks_two_gpus_over_rccl():
+    """The N > 1 path for real: one process per GPU, each runs its own window shard through msm_amd_multiexp_shard_async on its own
+    MI355X, the 144-byte partials cross xGMI in ONE RCCL all_gather, every rank adds them on the host."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [ctx.Process(target=_rccl_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert len({h for _, _, h in res}) == 1

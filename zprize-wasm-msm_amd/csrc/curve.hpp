@@ -45,7 +45,12 @@ struct XYZZ {
     // 2*(x,y) for an affine, non-infinite point (mdbl-2008-s-1, a = 0).  Rare on the hot path (only
     // when a bucket meets the same point twice in a row), so kept out of line on the device.
 #if defined(__HIP_DEVICE_COMPILE__)
-    __device__ __noinline__ static XYZZ dbl_affine(F x, F y) { return dbl_affine_inl(x, y); }
+    // by-value operands of an out-of-line device function: two 384-byte structs passed this way arrived corrupted in the callee
+    // (DESIGN.md section 7); anything wider than MSM_BYVALUE_MAX bytes must travel by reference (add_to / dbl_to below)
+    __device__ __noinline__ static XYZZ dbl_affine(F x, F y) {
+        static_assert(2 * sizeof(F) <= MSM_BYVALUE_MAX, "pass wide operands of out-of-line device functions by reference");
+        return dbl_affine_inl(x, y);
+    }
 #else
     static XYZZ dbl_affine(const F& x, const F& y) { return dbl_affine_inl(x, y); }
 #endif

@@ -204,6 +204,7 @@ struct XYZZU {
     // (2 waves/SIMD); inline the kernel needs 165 (3 waves).  G2 keeps it out of line (code size).
     template <class X2, class Y2>
     __host__ __device__ __noinline__ static XYZZU dbl_affine(X2 x_in, Y2 y_in) {
+        static_assert(sizeof(X2) + sizeof(Y2) <= MSM_BYVALUE_MAX, "pass wide operands of out-of-line device functions by reference");
         return dbl_affine_inl(x_in, y_in);
     }
     template <class X2, class Y2>

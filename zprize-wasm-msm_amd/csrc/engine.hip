@@ -156,14 +156,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.half = 1u << (g.c - 1);
     g.shard = a.shard;
     g.nshards = a.nshards;
-    // GLV path: 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_digits_glv).  Same number of bucket
+    // GLV path -- only for callers that vouch for their bases (flag MSM_AMD_BASES_IN_SUBGROUP, or option "glv" = 2): k*P = k1*P + k2*phi(P)
+    // with k reduced mod r holds in the order-r subgroup only, while the reference's multiexp is plain integer arithmetic, exact for
+    // ANY point of the curve (G1 has a ~2^126 cofactor).  Without the flag the engine keeps the reference's semantics.
+    // 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_digits_glv).  Same number of bucket
     // additions, half the buckets.  It pays where the bucket reduction dominates (n <= 2^17: 8-15 % per call); from 2^18 up
     // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
     // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2
     // forces the path (tests, experiments).
     bool use_glv = false;
     if constexpr (GlvField<F>::value)
-        use_glv = ctx->glv_mode != 0 && !ctx->sort_atomic && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+        use_glv = (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && !ctx->sort_atomic && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
                   (a.n <= (1u << 17) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
     const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
@@ -174,6 +177,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.Wl = 0;
     for (uint32_t w = 0; w < g.W; ++w)
         if (w % g.nshards == g.shard) ++g.Wl;
+    // (pair, window) positions -- Mscan, offset, delta, the indices into tmp/sorted -- are 32-bit: the entries of one pass must
+    // number fewer than 2^32 (17 windows x 2^27 points fit; 33 windows of 64-byte scalars or a forced narrow window would wrap)
+    if ((uint64_t)g.Wl * nv >= (1ull << 32)) {
+        msm_set_err(ctx, "windows x points of one pass must stay below 2^32 (fewer points per call, a wider window, or the synchronous entry point with option \"slice\")");
+        return MSM_AMD_EINVAL;
+    }
     ctx->geometry[0] = g.c;
     ctx->geometry[1] = g.W;
     ctx->geometry[2] = g.half;

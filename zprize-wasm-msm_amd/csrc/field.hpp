@@ -30,6 +30,10 @@
 
 #define MSM_HD __host__ __device__ __forceinline__
 #define MSM_D __device__ __forceinline__
+// Largest total of by-value struct operands an out-of-line (__noinline__) device function may take: two 384-byte XYZZ<Fp2> structs
+// passed by value arrived corrupted in the callee on gfx950 / ROCm 7.2, 256-byte ones were fine.  Static
+// asserts at the by-value functions and tools/check_code_objects.py (source scan) enforce it.
+#define MSM_BYVALUE_MAX 256
 
 namespace msm {
 

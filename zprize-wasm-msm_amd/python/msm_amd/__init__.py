@@ -27,6 +27,7 @@ FLAG_JACOBIAN = 1
 FLAG_DEVICE = 2
 FLAG_DEVICE_BASES = 4
 FLAG_FFT_INVERSE = 8
+FLAG_BASES_IN_SUBGROUP = 16
 
 
 class MsmAmdError(RuntimeError):
@@ -212,13 +213,20 @@ class Curve:
     def affine_bytes(self, group): return 2 * self.n8 * group
     def jacobian_bytes(self, group): return 3 * self.n8 * group
 
-    def _multiexp(self, group, flags, bases, scalars, scalar_size, n):
-        pb, dev_b, kb = _as_ptr(bases)
-        ps, dev_s, ks = _as_ptr(scalars)
+    @staticmethod
+    def _residency_flags(dev_b, dev_s):
+        """MSM_AMD_DEVICE_PTRS when both inputs are device memory, MSM_AMD_DEVICE_BASES when only the bases are (the resident SRS of a
+        prover, scalars from the host each call); device scalars with host bases is not a combination the engine has."""
         if dev_s and not dev_b:
             raise MsmAmdError("device scalars with host bases is not supported")
         if dev_b:
-            flags |= FLAG_DEVICE if dev_s else FLAG_DEVICE_BASES     # resident bases, scalars from the host each call
+            return FLAG_DEVICE if dev_s else FLAG_DEVICE_BASES
+        return 0
+
+    def _multiexp(self, group, flags, bases, scalars, scalar_size, n, in_subgroup=False):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        flags |= self._residency_flags(dev_b, dev_s) | (FLAG_BASES_IN_SUBGROUP if in_subgroup else 0)
         out = ctypes.create_string_buffer(self.jacobian_bytes(group))
         self.eng._chk(self.eng.L.msm_amd_multiexp(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, out))
         return out.raw
@@ -236,19 +244,20 @@ class Curve:
         return out.raw
 
     # --- pipelined form: up to two calls in flight per engine (reduction of one overlaps accumulation of the next)
-    def multiexp_async(self, group, bases, scalars, scalar_size, n, jacobian_bases=False):
+    def multiexp_async(self, group, bases, scalars, scalar_size, n, jacobian_bases=False, in_subgroup=False):
         pb, dev_b, kb = _as_ptr(bases)
         ps, dev_s, ks = _as_ptr(scalars)
         if dev_b != dev_s:
             raise MsmAmdError("bases and scalars must both be host or both be device buffers")
-        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0) | (FLAG_BASES_IN_SUBGROUP if in_subgroup else 0)
         t = ctypes.c_uint64()
         self.eng._chk(self.eng.L.msm_amd_multiexp_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, ctypes.byref(t)))
         return Ticket(self, group, t.value, (kb, ks))
 
     # --- the reference's export names -------------------------------------------------------
-    def g1m_multiexp(self, bases, scalars, scalar_size, n): return self._multiexp(1, FLAG_JACOBIAN, bases, scalars, scalar_size, n)
-    def g1m_multiexpAffine(self, bases, scalars, scalar_size, n): return self._multiexp(1, 0, bases, scalars, scalar_size, n)
+    # (in_subgroup=True: the caller vouches that the bases lie in the order-r subgroup -- MSM_AMD_BASES_IN_SUBGROUP, include/msm_amd.h)
+    def g1m_multiexp(self, bases, scalars, scalar_size, n, in_subgroup=False): return self._multiexp(1, FLAG_JACOBIAN, bases, scalars, scalar_size, n, in_subgroup)
+    def g1m_multiexpAffine(self, bases, scalars, scalar_size, n, in_subgroup=False): return self._multiexp(1, 0, bases, scalars, scalar_size, n, in_subgroup)
     def g2m_multiexp(self, bases, scalars, scalar_size, n): return self._multiexp(2, FLAG_JACOBIAN, bases, scalars, scalar_size, n)
     def g2m_multiexpAffine(self, bases, scalars, scalar_size, n): return self._multiexp(2, 0, bases, scalars, scalar_size, n)
 
@@ -271,7 +280,7 @@ class Curve:
     def multiexp_shard(self, group, bases, scalars, scalar_size, n, shard, nshards, jacobian_bases=False):
         pb, dev_b, kb = _as_ptr(bases)
         ps, dev_s, ks = _as_ptr(scalars)
-        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | self._residency_flags(dev_b, dev_s)
         out = ctypes.create_string_buffer(self.jacobian_bytes(group))
         self.eng._chk(self.eng.L.msm_amd_multiexp_shard(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
                                                         shard, nshards, out))
@@ -280,7 +289,7 @@ class Curve:
     def multiexp_shard_async(self, group, bases, scalars, scalar_size, n, shard, nshards, jacobian_bases=False):
         pb, dev_b, kb = _as_ptr(bases)
         ps, dev_s, ks = _as_ptr(scalars)
-        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | self._residency_flags(dev_b, dev_s)
         t = ctypes.c_uint64()
         self.eng._chk(self.eng.L.msm_amd_multiexp_shard_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n,
                                                               shard, nshards, ctypes.byref(t)))
