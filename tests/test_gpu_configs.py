@@ -101,9 +101,9 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
 def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     """The reference's g1m_multiexpAffine is integer arithmetic on curve points: exact for points outside the order-r subgroup too.
     The engine's GLV schedule (k mod r, endomorphism) is not -- so it only runs for callers that pass MSM_AMD_BASES_IN_SUBGROUP.
-    n = 2048 sits in the range where the GLV schedule is the default for flagged calls."""
+    n = 4500 sits in the range (16-bit windows, n <= 2^17) where the GLV schedule is the default for flagged calls."""
     import msm_amd
-    curve, group, n = "bls12381", 1, 2048
+    curve, group, n = "bls12381", 1, 4500
     C = eng.curve(curve)
     O = orc.Oracle(curve, group)
     with open(os.path.join(gu.GOLDEN, "golden_ingroup.json")) as f:

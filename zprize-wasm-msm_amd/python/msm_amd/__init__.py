@@ -16,6 +16,7 @@ raises.  PyTorch is optional plumbing: CUDA tensors are accepted as device-resid
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc", "libmsm_amd.so"))
@@ -43,6 +44,15 @@ def load_library(path=None):
     if _lib is not None:
         return _lib
     path = path or os.environ.get("MSM_AMD_LIB", _LIB_PATH)
+    # Library load order matters in a process that also uses torch on the GPU: torch ships its own HIP runtime, and if the engine's
+    # (/opt/rocm's libamdhip64) is loaded first, torch's later finds "no ROCm-capable device".  Loaded the other way round both
+    # work (the engine then runs on torch's runtime).  So when torch is installed it is imported first -- importing does not touch
+    # the GPU.  MSM_AMD_NO_TORCH=1 skips this (hosts that never use torch).
+    if "torch" not in sys.modules and os.environ.get("MSM_AMD_NO_TORCH", "") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise MsmAmdError(f"HIP engine library not found at {path}; build it with `python __graft_entry__.py` "
                           "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
