@@ -64,7 +64,7 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
     try:
         full = _call(eng, C, group, pts.ptr, sp, n)
         geom = eng.geometry()
-        assert geom["entries"] > n * 14                        # every window of every pair was scattered
+        assert geom["entries"] > n * (geom["windows"] - 2)     # (nearly) every window of every pair was scattered
         # (1) the multi-GPU decomposition on one GPU
         parts = b"".join(C.multiexp_shard(group, pts, sc, 32, n, r, 8) for r in range(8))
         assert msm_amd.combine(curve, group, parts) == full

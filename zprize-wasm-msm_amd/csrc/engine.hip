@@ -68,13 +68,17 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
     if (forced) {
         c = forced;
     } else {
-        // measured on MI355X (profiles/r01_sweep_window_bits.log): the bucket reduction costs ~1.1 ms whatever n is
-        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits.
-        c = n >= 4096 ? 16 : 8;
+        // measured on MI355X (profiles/r01_sweep_window_bits*.log, r02_sweep_window_bits_large_n.txt): the bucket reduction costs
+        // about the same whatever n is (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below
+        // that, 8 bits.  From n = 2^23 the additions saved by fewer, wider windows (14 windows of 19 bits / 13 of 20 over a 255-bit
+        // scalar instead of 16 of 16 bits) outweigh the 8-16 times larger bucket arrays and their reduction: n = 2^24 39.0 ms
+        // (c = 19) against 42.7, n = 2^26 145.3 ms (c = 20) against 177.3.  The reference widens its window with n too
+        // (build_multiexp.js:275-280).
+        c = n >= (1u << 25) ? 20 : n >= (1u << 23) ? 19 : n >= 4096 ? 16 : 8;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
-    if (c > 16) c = 16;   // 16-bit digit codes, 15-bit bucket index
+    if (c > (uint32_t)MAX_WINDOW_BITS) c = MAX_WINDOW_BITS;   // sign + 8 coarse + 12 fine bits of bucket index (sort_kernels.hpp)
     return c;
 }
 
@@ -166,7 +170,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // forces the path (tests, experiments).
     bool use_glv = false;
     if constexpr (GlvField<F>::value)
-        use_glv = (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && !ctx->sort_atomic && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+        use_glv = (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
                   (a.n <= (1u << 17) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
     const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
@@ -194,7 +198,6 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         return 0;
     }
     const uint32_t NB = g.Wl * g.half;
-    const bool fast = (a.scalar_size % 4 == 0) && (((uintptr_t)d_scalars & 3) == 0);
 
     HIPCHK(ctx, hipEventRecord(sl->ev[0], st));
     // ---- Jacobian bases -> affine
@@ -214,21 +217,16 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     HIPCHK(ctx, hipEventRecord(sl->ev[1], st));
 
-    const uint32_t ntiles = (NB + SCAN_TILE - 1) / SCAN_TILE;
     if (int rc = ensure(ctx, sl->d_count, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_cursor, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_tiles, (size_t)ntiles * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nv * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
     uint32_t* count = (uint32_t*)sl->d_count.p;
     uint32_t* offset = (uint32_t*)sl->d_offset.p;
-    uint32_t* cursor = (uint32_t*)sl->d_cursor.p;
     uint32_t* order = (uint32_t*)sl->d_order.p;
     uint32_t* bins = (uint32_t*)sl->d_bins.p;
-    uint32_t* tiles = (uint32_t*)sl->d_tiles.p;
     uint32_t* sorted = (uint32_t*)sl->d_sorted.p;
 
     const uint32_t nblk = (a.n + 255) / 256;
@@ -244,58 +242,134 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
     const uint32_t split = w_split * g.half;                                               // first bucket of the second group
     HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_KEYS * 4, st));
-    if (ctx->sort_atomic) {
-        // ---- 1. digits + histogram (global atomics)
-        HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));
-        if (fast) k_histogram<true><<<nblk, 256, 0, st>>>(d_scalars, g, count);
-        else k_histogram<false><<<nblk, 256, 0, st>>>(d_scalars, g, count);
+    {
+        // ---- 1. populations of the (owned window, coarse bin) pairs -- digits recomputed from the scalars, never stored
+        SortGeom sg;
+        // fine key: 8 bits up to c = 17 (at c = 16: 128 coarse bins, spans of n / 128 entries -- one workgroup reads a span once up
+        // to n = 2^20 -- and runs of tile / 128 entries in the partition), then 8 coarse bits and the rest fine
+        sg.fbits = g.c - 1 <= 16u ? std::min(g.c - 1, 8u) : g.c - 1 - 8u;
+        sg.cbits = g.c - 1 - sg.fbits;
+        sg.cb = 1u << sg.cbits;
+        sg.nbins = g.Wl * sg.cb;
+        sg.idxbits = 1;
+        while ((1ull << sg.idxbits) < nv) ++sg.idxbits;
+        const bool e32 = sg.fbits + 1 + sg.idxbits <= 32;     // 4-byte partition entries {fine key | sign | index}
+        // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
+        // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
+        const bool wide = nv >= (1u << 19);
+        const uint32_t tile = wide ? 4096u : 1024u;
+        const uint32_t ntile = (nv + tile - 1) / tile;
+        const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * (e32 ? 4 : 8))) return rc;
+        if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_binstart, ((size_t)sg.nbins + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_bincur, (size_t)sg.nbins * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_desc, max_chunks * 8)) return rc;
+        if (int rc = ensure(ctx, sl->d_bcursor, (size_t)NB * 4)) return rc;
+        uint32_t* binhist = (uint32_t*)sl->d_binhist.p;
+        uint32_t* binstart = (uint32_t*)sl->d_binstart.p;
+        uint32_t* bincur = (uint32_t*)sl->d_bincur.p;
+        uint32_t* cpre = (uint32_t*)sl->d_cpre.p;
+        uint2* desc = (uint2*)sl->d_desc.p;
+        uint32_t* bcursor = (uint32_t*)sl->d_bcursor.p;
+        // where the digits come from: 0 = any scalar size / bit range (bits read from memory per window), 8 = whole 32-byte scalars in
+        // registers, 4 = the 16-byte halves of the GLV schedule
+        const uint8_t* d_items = d_scalars;
+        int nw = 0;
+        if (use_glv) {
+            if (int rc = ensure(ctx, sl->d_halves, (size_t)nv * 16)) return rc;
+            k_glv_halves<<<nblk, 256, 0, st>>>(d_scalars, a.n, (uint4*)sl->d_halves.p);
+            d_items = (const uint8_t*)sl->d_halves.p;
+            nw = 4;
+        } else if (a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && (((uintptr_t)d_scalars & 15) == 0)) {
+            nw = 8;
+        }
+        const size_t hist_lds = (size_t)sg.nbins * 4;
+        if (hist_lds > 64 * 1024) {
+            msm_set_err(ctx, "too many windows x coarse bins for the histogram kernel (use a wider window)");
+            return MSM_AMD_EINVAL;
+        }
+        HIPCHK(ctx, hipMemsetAsync(binhist, 0, (size_t)sg.nbins * 4, st));
+#define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist)
+        if (wide) {
+            if (nw == 8) MSM_TILE_HIST(8, 1024);
+            else if (nw == 4) MSM_TILE_HIST(4, 1024);
+            else MSM_TILE_HIST(0, 1024);
+        } else {
+            if (nw == 8) MSM_TILE_HIST(8, 256);
+            else if (nw == 4) MSM_TILE_HIST(4, 256);
+            else MSM_TILE_HIST(0, 256);
+        }
+#undef MSM_TILE_HIST
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
-        // ---- 2. scan + order
-        k_scan_tile_sums<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles);
-        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, ntiles);
-        k_scan_apply<<<ntiles, SCAN_BLOCK, 0, st>>>(count, NB, tiles, offset, cursor);
-        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
-        k_order_scan<<<1, 1024, 0, st>>>(bins);
-        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
+        // ---- 2. bin starts
+        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur);
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
-        // ---- 3. scatter
-        if (fast) k_scatter<true><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
-        else k_scatter<false><<<nblk, 256, 0, st>>>(d_scalars, g, cursor, sorted);
-        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
-    } else {
-        // ---- 1. digit codes + coarse histogram
-        const uint32_t fine_bits = std::min(8u, g.c - 1);
-        const uint32_t cb = g.half >> fine_bits;                      // coarse bins per window (<= 128)
-        const uint32_t stile = (nv + SORT_TILE - 1) / SORT_TILE;
-        const size_t NM = (size_t)g.Wl * cb * stile;                   // count matrix entries (+1 for the total)
-        const uint32_t mtiles = (uint32_t)((NM + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        if (int rc = ensure(ctx, sl->d_dig, (size_t)g.Wl * nv * 2)) return rc;
-        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * 8)) return rc;
-        if (int rc = ensure(ctx, sl->d_M, (NM + 1) * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_Mscan, (NM + 1) * 4 * 2)) return rc;
-        if (int rc = ensure(ctx, sl->d_tiles, (size_t)std::max(mtiles, ntiles) * 4)) return rc;
-        tiles = (uint32_t*)sl->d_tiles.p;
-        uint16_t* dig = (uint16_t*)sl->d_dig.p;
-        uint64_t* tmp = (uint64_t*)sl->d_tmp.p;
-        uint32_t* M = (uint32_t*)sl->d_M.p;
-        uint32_t* Mscan = (uint32_t*)sl->d_Mscan.p;
-        uint32_t* Mdummy = Mscan + (NM + 1);
-        const bool c16 = g.c == 16 && a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && g.W == 17 && (((uintptr_t)d_scalars & 15) == 0);
-        if (use_glv) k_digits_glv<<<nblk, 256, 0, st>>>(d_scalars, a.n, g, dig);
-        else if (c16) k_digits_c16<<<nblk, 256, 0, st>>>(d_scalars, g, dig);
-        else if (fast) k_digits<true><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
-        else k_digits<false><<<nblk, 256, 0, st>>>(d_scalars, g, dig);
-        HIPCHK(ctx, hipMemsetAsync(M + NM, 0, 4, st));
-        k_coarse_hist<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, M);
-        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
-        // ---- 2. scan of the count matrix
-        k_scan_tile_sums<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles);
-        k_scan_tiles<<<1, SCAN_BLOCK, 0, st>>>(tiles, mtiles);
-        k_scan_apply<<<mtiles, SCAN_BLOCK, 0, st>>>(M, (uint32_t)(NM + 1), tiles, Mscan, Mdummy);
-        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
-        // ---- 3. coarse scatter, fine sort (emits count/offset), ordering by population
-        k_coarse_scatter<<<dim3(stile, g.Wl), SORT_BLOCK, 0, st>>>(dig, nv, fine_bits, cb, stile, Mscan, tmp);
-        k_fine_sort<<<g.Wl * cb, SORT_BLOCK, 0, st>>>(tmp, Mscan, stile, g.Wl * cb, fine_bits, cb, g.half, sorted, count, offset);
+        // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
+        // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
+        // 8-byte ones; the CU has 160 KB and hosts one 1024-lane workgroup)
+#define MSM_TILE_SCATTER(NW, BL, E, GW)                                                                                              \
+    do {                                                                                                                             \
+        constexpr size_t lds_ = tile_scatter_lds<E>(4 * BL, GW, BL);                                                                  \
+        if (lds_ > 64 * 1024)                                                                                                         \
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<NW, 4, BL, E, GW>),                         \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                                  \
+        k_tile_scatter<NW, 4, BL, E, GW><<<ntile, BL, lds_, st>>>(d_items, g, sg, bincur, (E*)sl->d_tmp.p);                           \
+    } while (0)
+#define MSM_TILE_SCATTER_E(NW, BL)          \
+    do {                                    \
+        if (e32) MSM_TILE_SCATTER(NW, BL, uint32_t, 4); \
+        else MSM_TILE_SCATTER(NW, BL, uint2, 2);        \
+    } while (0)
+        if (wide) {
+            if (nw == 8) MSM_TILE_SCATTER_E(8, 1024);
+            else if (nw == 4) MSM_TILE_SCATTER_E(4, 1024);
+            else MSM_TILE_SCATTER_E(0, 1024);
+        } else {
+            if (nw == 8) MSM_TILE_SCATTER_E(8, 256);
+            else if (nw == 4) MSM_TILE_SCATTER_E(4, 256);
+            else MSM_TILE_SCATTER_E(0, 256);
+        }
+#undef MSM_TILE_SCATTER_E
+#undef MSM_TILE_SCATTER
+        const uint32_t nf = 1u << sg.fbits;
+        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * BIG_CHUNK) * 4;
+        // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
+        // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
+        // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
+        const uint32_t tb = g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u;   // scalar bits in the top window
+        const uint64_t mean_span = (uint64_t)nv / sg.cb;
+        const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1;
+        if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+        }
+        if (!expect_long || ctx->sort_big == 2) {
+            if (e32) k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+            else k_fine_small<uint2, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        } else {
+            if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+            }
+            const uint32_t big_grid = (uint32_t)std::min<size_t>(max_chunks, 4096);
+            HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
+            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, cpre);
+            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, desc);
+            if (e32) {
+                k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+                k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
+            } else {
+                k_fine_small<uint2, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+                k_big_hist<uint2><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
+            }
+            k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
+            if (e32) k_big_scatter<uint32_t><<<big_grid, SORT_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            else k_big_scatter<uint2><<<big_grid, SORT_BLOCK, big_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+        }
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scan<<<1, 1024, 0, st>>>(bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
@@ -314,7 +388,21 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // the few buckets of a narrow top window when the scalar width is not a multiple of c -- are cut into segments, which
     // bounds the longest dependent chain of additions.
     const uint32_t mean = (nv + g.half - 1) / g.half;
+    // A top window that the scalar bits only partly fill (c = 20 over 256 bits: 16 bits of 20) uses 2^tb of its buckets, each
+    // 2^(c-1-tb) times denser than the rest.  When those are many (>= 4096: 64 waves) they run as ordinary lanes with longer
+    // chains -- started first, since buckets are ordered by falling population -- rather than as segments for the tail kernels
+    // (one workgroup iteration per over-long bucket: 32768 of them cost 40 ms at n = 2^24, profiles/r02_sweep_c_first.txt).
     uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, mean + 8u * (uint32_t)std::ceil(std::sqrt((double)mean)) + 8u);
+    if (!ctx->force_seg) {
+        const uint32_t tb = g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u;   // scalar bits in the top window
+        if (tb >= 12 && tb < g.c - 1) {
+            // twice the nominal density: scalars below a 255-bit group order leave the top bit clear
+            const uint32_t dense = 2u * (uint32_t)(((uint64_t)nv + (1ull << tb) - 1) >> tb);
+            const uint32_t seg_hi = dense + 8u * (uint32_t)std::ceil(std::sqrt((double)dense)) + 8u;
+            const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nv) / 200000u, 1u << 20);   // ~ a fifth of a lane's share of the launch
+            seg = std::max(seg, std::min(seg_hi, cap));
+        }
+    }
     const size_t max_segs = (size_t)g.Wl * nv / seg + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
@@ -750,7 +838,6 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (const char* e = getenv("MSM_AMD_REDUCE_L")) ctx->force_L = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
-    if (const char* e = getenv("MSM_AMD_SORT")) ctx->sort_atomic = (strcmp(e, "atomic") == 0);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -845,8 +932,8 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "window_bits")) return msm_amd_set_window_bits(ctx, value);
     if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
     if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
-    if (!strcmp(name, "sort_atomic")) { ctx->sort_atomic = value != 0; return 0; }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
+    if (!strcmp(name, "sort_big")) { ctx->sort_big = value > 2 ? 0 : (int)value; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split2")) { ctx->no_split2 = value == 0; return 0; }
     if (!strcmp(name, "split2_nb")) { ctx->split2_nb = value; return 0; }
@@ -868,7 +955,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
 }
 
 int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
-    if (!ctx || c > 16) return MSM_AMD_EINVAL;
+    if (!ctx || c > (uint32_t)MAX_WINDOW_BITS) return MSM_AMD_EINVAL;
     ctx->force_c = c;
     return 0;
 }

@@ -33,9 +33,9 @@ using namespace msm;
 // two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
 // the sort + accumulation of the next call (throughput-bound, stream A).
 struct Slot {
-    DevBuf d_dig, d_tmp, d_M, d_Mscan, d_tailctl, d_work, d_biglist, d_segout;
+    DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
-    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_cursor, d_order, d_bins, d_tiles, d_sorted, d_buckets, d_partials;
+    DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts
@@ -52,8 +52,8 @@ struct Slot {
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
-    DevBuf* bufs[21] = {&d_xbeta, &d_dig, &d_tmp, &d_M, &d_Mscan, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
-                        &d_affine, &d_count, &d_offset, &d_cursor, &d_order, &d_bins, &d_tiles, &d_sorted, &d_buckets, &d_partials};
+    DevBuf* bufs[23] = {&d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+                        &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
 
 struct msm_amd_ctx {
@@ -81,7 +81,7 @@ struct msm_amd_ctx {
     uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
-    int sort_atomic = 0;    // MSM_AMD_SORT=atomic selects the global-atomics scatter (A/B comparisons)
+    int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
     float timings[8] = {};
     uint32_t geometry[6] = {};
 };

@@ -1,11 +1,37 @@
 // sort_kernels.hpp -- stages 1-3 of the engine (scalar windowing = getChunk, build_multiexp.js:25-94, and
-// the radix-c bucket scatter that replaces the reference's table walk :186-233): digit extraction with signed recoding, the two-pass
-// LDS radix partition by bucket, the scans and the ordering of buckets by population.  HBM-bound kernels; included by engine.hip only.
+// the radix-c bucket scatter that replaces the reference's table walk :186-233): signed-digit recoding of the scalars and a
+// two-level LDS radix partition of the (pair, window) entries by bucket.  HBM-bound kernels; included by engine.hip only.
+//
+//   k_glv_halves      (GLV schedule only) scalar -> two signed 127-bit halves, written once as 16-byte items
+//   k_tile_hist       one workgroup per TILE of scalars, all windows: digits are recomputed from the scalar held in registers
+//                     (never stored), LDS histogram over the COARSE bits of the bucket index, one global atomic per non-empty
+//                     (window, bin) -> bin populations;  k_bin_scan: their exclusive scan = bin starts and cursors
+//   k_tile_scatter    same tiles, same digits: a counting sort of the tile's entries of four windows at a time in LDS, every
+//                     (tile, window, bin) run reserves its place with one atomic on the bin's cursor and is stored by consecutive
+//                     lanes -> partition entries {fine key | sign | index}, 4 bytes while fine bits + 1 + index bits <= 32
+//                     (n <= 2^23 at c = 16), 8 bytes beyond
+//   k_fine_small      one workgroup per (window, coarse bin) whose span fits the registers of a workgroup (<= FINE_CAP entries:
+//                     every call up to n ~ 2^20): the span is read ONCE, bucket count/offset come from an LDS histogram, the
+//                     span is permuted in LDS and written back as one coalesced stream
+//   k_big_*           longer spans (large n, the dense bins of a partly used top window, adversarial scalars): cut into chunks
+//                     that workgroups sort in parallel (histogram pass, per-bin offsets, scatter pass)
+//   k_order_*         buckets ordered by population so that the 64 lanes of an accumulation wave run equal trip counts
+// Global atomics only on a few thousand bin / bucket cursors (one per run, never per entry); every data access is a coalesced
+// stream or a run inside one bin.  The order of the entries inside a bucket is not deterministic -- the sums do not depend on it.
+//
+// Round 1 kept 16-bit digit codes in HBM (written once, read twice), 8-byte entries (written once, read twice) and a (tile x bin)
+// count matrix with its scan: 713 MB per call at n = 2^20 against 101 MB algorithmic.  Recomputing the digits and reading each
+// span once brings that to ~270 MB, and nothing is 16 bits wide any more: windows up to 21 bits (8 coarse + 12 fine bits).
 #pragma once
 #include "engine_common.hpp"
 #include "glv.hpp"
 
 namespace msm {
+
+constexpr int SORT_BLOCK = 256;
+constexpr int COARSE_MAX = 256;        // coarse bins per window (8 bits)
+constexpr int FINE_MAX_BITS = 12;      // fine buckets per coarse bin (4096)
+constexpr int MAX_WINDOW_BITS = 1 + 8 + FINE_MAX_BITS;   // sign + coarse + fine = 21
 
 // Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
 MSM_D uint32_t scalar_bits(const uint8_t* scalars, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
@@ -18,124 +44,78 @@ MSM_D uint32_t scalar_bits(const uint8_t* scalars, const Geom& g, uint32_t i, ui
         if (byte + b < g.scalar_size) w |= (uint64_t)s[byte + b] << (8 * b);
     return (uint32_t)(w >> (pos & 7)) & ((1u << nb) - 1u);
 }
-// fast path: scalar_size % 4 == 0 and 4-byte aligned scalars
-MSM_D uint32_t scalar_bits32(const uint32_t* scalars32, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
-    if (nb == 0) return 0;
-    uint32_t words = g.scalar_size >> 2;
-    const uint32_t* s = scalars32 + (size_t)i * words;
-    uint32_t wi = pos >> 5;
-    uint32_t w0 = s[wi];
-    uint32_t w1 = (wi + 1 < words) ? s[wi + 1] : 0u;
-    uint64_t w = ((uint64_t)w1 << 32) | w0;
-    return (uint32_t)(w >> (pos & 31)) & ((1u << nb) - 1u);
-}
-
-// Signed radix-2^c recoding of scalar i; calls f(window, bucket_in_window (0-based), negative).
-template <bool FAST, class Fn>
-MSM_D void for_each_digit(const uint8_t* scalars, const Geom& g, uint32_t i, Fn&& f) {
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < g.W; ++w) {
-        uint32_t off = w * g.c;
-        uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
-        uint32_t raw = FAST ? scalar_bits32(reinterpret_cast<const uint32_t*>(scalars), g, i, g.bit_lo + off, nb)
-                            : scalar_bits(scalars, g, i, g.bit_lo + off, nb);
-        raw += carry;
-        bool negd = raw > g.half;
-        uint32_t mag = negd ? (1u << g.c) - raw : raw;
-        carry = negd ? 1u : 0u;
-        if (mag != 0 && (w % g.nshards) == g.shard) f(w / g.nshards, mag - 1, negd);
-    }
-}
 
 // ------------------------------------------------------------------------------------------
-// stage 1 / 3: histogram and scatter
+// Digit source of one tile: ITEMS items per lane, consumed window by window from the low end.
+//   NW = 8: whole 32-byte scalars held in registers (16-byte aligned input), shifted right by c after every window
+//   NW = 4: 16-byte GLV halves (bit 127 = sign of the half), same
+//   NW = 0: any scalar size / bit range: the bits of every window are read from memory (L1/L2-resident tile)
+// next() returns the signed digit of the current window: magnitude in [0, 2^(c-1)] and whether it is negative
+// (digit in [-2^(c-1), 2^(c-1)], carry into the next window).
 // ------------------------------------------------------------------------------------------
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_histogram(const uint8_t* __restrict__ scalars, Geom g, uint32_t* __restrict__ count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n) return;
-    for_each_digit<FAST>(scalars, g, i, [&](uint32_t wl, uint32_t b, bool) { atomicAdd(&count[wl * g.half + b], 1u); });
-}
+template <int NW, int ITEMS, int BLOCK>
+struct DigitSource {
+    uint32_t w[ITEMS][NW > 0 ? NW : 1];
+    uint32_t carry;   // bit k: carry of item k
+    uint32_t flip;    // bit k: the item's own sign (GLV halves)
+    uint32_t valid;   // bit k: item exists
+    uint32_t first;   // index of this lane's item 0 (items are first + k * BLOCK)
 
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_scatter(const uint8_t* __restrict__ scalars, Geom g, uint32_t* __restrict__ cursor,
-                                                  uint32_t* __restrict__ sorted) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n) return;
-    for_each_digit<FAST>(scalars, g, i, [&](uint32_t wl, uint32_t b, bool negd) {
-        uint32_t pos = atomicAdd(&cursor[wl * g.half + b], 1u);
-        sorted[pos] = i | (negd ? 0x80000000u : 0u);
-    });
-}
-
-
-// ------------------------------------------------------------------------------------------
-// stage 1-3, LDS path (default): digits -> two-pass radix partition by bucket.
-//   k_digits          one lane per scalar, all windows: 16-bit signed-digit codes, window-major
-//                     (code = sign<<15 | (magnitude-1); 0xFFFF = zero digit)
-//   k_coarse_hist     per (tile, window): LDS histogram over the top bits of the bucket index
-//   (scan)            exclusive scan of the (window, coarse bin, tile) count matrix
-//   k_coarse_scatter  per (tile, window): local counting sort in LDS, then each (tile, bin) run is
-//                     written with consecutive lanes -> coalesced 8-byte entries {fine key, index}
-//   k_fine_sort       one workgroup per (window, coarse bin): histogram of the low bucket bits,
-//                     bucket count/offset tables, scatter of the point indices inside the bin's
-//                     (L2-resident) span of `sorted`
-// No global atomics; every global access is a coalesced stream or a scatter confined to one bin.
-// ------------------------------------------------------------------------------------------
-constexpr int SORT_BLOCK = 256;
-constexpr int SORT_ITEMS = 16;
-constexpr int SORT_TILE = SORT_BLOCK * SORT_ITEMS;   // digits per workgroup
-constexpr int COARSE_MAX = 128;                      // coarse bins per window (c <= 16, 8 fine bits)
-constexpr uint32_t DIGIT_ZERO = 0xFFFFu;
-
-template <bool FAST>
-__global__ void __launch_bounds__(256) k_digits(const uint8_t* __restrict__ scalars, Geom g, uint16_t* __restrict__ dig) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n) return;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < g.W; ++w) {
-        uint32_t off = w * g.c;
-        uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
-        uint32_t raw = FAST ? scalar_bits32(reinterpret_cast<const uint32_t*>(scalars), g, i, g.bit_lo + off, nb)
-                            : scalar_bits(scalars, g, i, g.bit_lo + off, nb);
-        raw += carry;
-        bool negd = raw > g.half;
-        uint32_t mag = negd ? (1u << g.c) - raw : raw;
-        carry = negd ? 1u : 0u;
-        if ((w % g.nshards) == g.shard) {
-            uint32_t code = mag == 0 ? DIGIT_ZERO : ((negd ? 0x8000u : 0u) | (mag - 1));
-            dig[(size_t)(w / g.nshards) * g.n + i] = (uint16_t)code;
-        }
-    }
-}
-
-// c == 16, 32-byte aligned scalars, whole scalar: the raw digits are the 16 half-words of the scalar (two 16-byte loads)
-__global__ void __launch_bounds__(256) k_digits_c16(const uint8_t* __restrict__ scalars, Geom g, uint16_t* __restrict__ dig) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= g.n) return;
-    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + (size_t)i * 2;
-    uint4 lo = sp[0], hi = sp[1];
-    uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    uint32_t carry = 0;
+    MSM_D void load(const uint8_t* __restrict__ scalars, const Geom& g, uint32_t tile_base) {
+        carry = flip = valid = 0;
+        first = tile_base + threadIdx.x;
 #pragma unroll
-    for (uint32_t w = 0; w < 17; ++w) {
-        uint32_t raw = w < 16 ? ((wd[w >> 1] >> (16 * (w & 1))) & 0xFFFFu) : 0u;
-        raw += carry;
-        bool negd = raw > 0x8000u;
-        uint32_t mag = negd ? 0x10000u - raw : raw;
-        carry = negd ? 1u : 0u;
-        if ((w % g.nshards) == g.shard) {
-            uint32_t code = mag == 0 ? DIGIT_ZERO : ((negd ? 0x8000u : 0u) | (mag - 1));
-            dig[(size_t)(w / g.nshards) * g.n + i] = (uint16_t)code;
+        for (int k = 0; k < ITEMS; ++k) {
+            const uint32_t i = first + k * BLOCK;
+            if (i < g.n) valid |= 1u << k;
+            if constexpr (NW > 0) {
+                if (i < g.n) {
+                    const uint4* sp = reinterpret_cast<const uint4*>(scalars) + (size_t)i * (NW / 4);
+#pragma unroll
+                    for (int q = 0; q < NW / 4; ++q) {
+                        uint4 v = sp[q];
+                        w[k][4 * q] = v.x;
+                        w[k][4 * q + 1] = v.y;
+                        w[k][4 * q + 2] = v.z;
+                        w[k][4 * q + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) w[k][q] = 0;
+                }
+                if constexpr (NW == 4) {
+                    if (w[k][3] >> 31) flip |= 1u << k;
+                    w[k][3] &= 0x7fffffffu;
+                }
+            }
         }
     }
-}
+    // digit of item k in window `win` (windows must be visited in order 0, 1, 2, ...)
+    MSM_D void next(const uint8_t* __restrict__ scalars, const Geom& g, int k, uint32_t win, uint32_t& mag, bool& neg) {
+        uint32_t raw;
+        if constexpr (NW > 0) {
+            raw = w[k][0] & ((1u << g.c) - 1u);   // bits beyond the scalar are zero by construction
+#pragma unroll
+            for (int q = 0; q < NW - 1; ++q) w[k][q] = __builtin_amdgcn_alignbit(w[k][q + 1], w[k][q], g.c);
+            w[k][NW - 1] >>= g.c;
+        } else {
+            const uint32_t off = win * g.c;
+            const uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
+            raw = (valid >> k) & 1u ? scalar_bits(scalars, g, first + k * BLOCK, g.bit_lo + off, nb) : 0u;
+        }
+        raw += (carry >> k) & 1u;
+        const bool negd = raw > g.half;
+        mag = negd ? (1u << g.c) - raw : raw;
+        carry = negd ? (carry | (1u << k)) : (carry & ~(1u << k));
+        neg = negd != (((flip >> k) & 1u) != 0);
+    }
+};
 
-// GLV path (BLS12-381 G1, c = 16, whole 32-byte scalars; SURVEY.md 8f rank 1, constants of build_glv.js:15-22): every
-// scalar is split into two signed 127-bit halves (glv::split_centered).  Virtual item 2i is (P_i, k1), item 2i+1 is
-// (phi(P_i), k2) with phi(x, y) = (beta*x, y): 2n items, 8 windows and no carry out of the last one -- the same number of
-// bucket additions as 16 windows over n items, but half the buckets to initialise, reduce and Horner-combine.
-__global__ void __launch_bounds__(256) k_digits_glv(const uint8_t* __restrict__ scalars, uint32_t n, Geom g, uint16_t* __restrict__ dig) {
+// GLV schedule (BLS12-381 G1; SURVEY.md 8f rank 1, constants of build_glv.js:15-22): every scalar is split into two signed
+// 127-bit halves (glv::split_centered).  Virtual item 2i is (P_i, k1), item 2i+1 is (phi(P_i), k2) with phi(x, y) = (beta*x, y):
+// 2n items of 128 bits, 8 windows of 16 bits and no carry out of the last one.  The halves are written once (|k| in bits
+// 0..126, the sign in bit 127) and the tile kernels read them like 16-byte scalars.
+__global__ void __launch_bounds__(256) k_glv_halves(const uint8_t* __restrict__ scalars, uint32_t n, uint4* __restrict__ halves) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint4* sp = reinterpret_cast<const uint4*>(scalars) + (size_t)i * 2;
@@ -144,25 +124,7 @@ __global__ void __launch_bounds__(256) k_digits_glv(const uint8_t* __restrict__ 
     uint32_t h[2][4];
     uint32_t sg = glv::split_centered(k, h[0], h[1]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        uint32_t carry = 0;
-        const bool sneg = ((sg >> j) & 1u) != 0;
-#pragma unroll
-        for (uint32_t w = 0; w < 8; ++w) {
-            uint32_t raw = (h[j][w >> 1] >> (16 * (w & 1))) & 0xFFFFu;
-            raw += carry;
-            // raw == 2^15 may be written +2^15 or -2^15 (+carry): take the form whose final sign is positive, because the
-            // code "negative, magnitude 2^15" (0xFFFF) is the zero-digit marker.  The halves are below 2^127 (top digit
-            // <= 0x5623), so this never carries out of the last window.
-            bool negd = raw > 0x8000u || (raw == 0x8000u && sneg);
-            uint32_t mag = negd ? 0x10000u - raw : raw;
-            carry = negd ? 1u : 0u;
-            if ((w % g.nshards) == g.shard) {
-                uint32_t code = mag == 0 ? DIGIT_ZERO : (((negd != sneg) ? 0x8000u : 0u) | (mag - 1));
-                dig[(size_t)(w / g.nshards) * g.n + 2 * i + j] = (uint16_t)code;
-            }
-        }
-    }
+    for (int j = 0; j < 2; ++j) halves[(size_t)2 * i + j] = make_uint4(h[j][0], h[j][1], h[j][2], h[j][3] | (((sg >> j) & 1u) << 31));
 }
 // x-coordinates of the endomorphism images: xbeta[i] = beta * x_i (y is shared with the original point)
 template <class F>
@@ -184,255 +146,436 @@ struct GlvField<Fp<Bls12381Fp>> {
     static constexpr bool value = true;
 };
 
-__global__ void __launch_bounds__(SORT_BLOCK) k_coarse_hist(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
-                                                              uint32_t ntile, uint32_t* __restrict__ M) {
-    __shared__ uint32_t h[COARSE_MAX];
-    const uint32_t wl = blockIdx.y, tile = blockIdx.x;
-    if (threadIdx.x < COARSE_MAX) h[threadIdx.x] = 0;
+// Layout of the partition: bucket index (0-based magnitude - 1, c-1 bits) = coarse bin (top cbits) || fine key (low fbits).
+struct SortGeom {
+    uint32_t cbits, fbits;   // c - 1 = cbits + fbits; cbits <= 8, fbits <= 12
+    uint32_t cb;             // coarse bins per window = 2^cbits
+    uint32_t nbins;          // owned windows x coarse bins
+    uint32_t idxbits;        // bits of an item index (4-byte entries: fine key above the sign bit at position idxbits)
+};
+
+// ------------------------------------------------------------------------------------------
+// k_tile_hist: binhist[wl * cb + bin] += entries of this tile that fall into (owned window wl, coarse bin)
+// (LDS histogram per tile, then one global atomic per non-empty (window, bin): ~2000 counters shared by all tiles)
+// ------------------------------------------------------------------------------------------
+template <int NW, int ITEMS, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ binhist) {
+    extern __shared__ uint32_t smem_u32[];
+    uint32_t* h = smem_u32;   // [Wl][cb]
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t s = threadIdx.x; s < sg.nbins; s += BLOCK) h[s] = 0;
     __syncthreads();
-    const uint16_t* d = dig + (size_t)wl * n;
-    const uint32_t base = tile * SORT_TILE;
+    DigitSource<NW, ITEMS, BLOCK> ds;
+    ds.load(scalars, g, tile * (ITEMS * BLOCK));
+    for (uint32_t w = 0; w < g.W; ++w) {
+        const bool owned = (w % g.nshards) == g.shard;
+        const uint32_t wl = w / g.nshards;
 #pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
-        if (i < n) {
-            uint32_t code = d[i];
-            if (code != DIGIT_ZERO) atomicAdd(&h[(code & 0x7FFFu) >> fine_bits], 1u);
+        for (int k = 0; k < ITEMS; ++k) {
+            uint32_t mag;
+            bool neg;
+            ds.next(scalars, g, k, w, mag, neg);
+            if (owned && mag != 0) atomicAdd(&h[wl * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
         }
     }
     __syncthreads();
-    if (threadIdx.x < cb) M[((size_t)wl * cb + threadIdx.x) * ntile + tile] = h[threadIdx.x];
-}
-
-__global__ void __launch_bounds__(SORT_BLOCK) k_coarse_scatter(const uint16_t* __restrict__ dig, uint32_t n, uint32_t fine_bits, uint32_t cb,
-                                                                 uint32_t ntile, const uint32_t* __restrict__ Mscan, uint64_t* __restrict__ tmp) {
-    __shared__ uint32_t h[COARSE_MAX];        // counts, then running cursors
-    __shared__ uint32_t lstart[COARSE_MAX];   // start of each bin inside the staged tile
-    __shared__ uint32_t delta[COARSE_MAX];    // global position of slot s = delta[bin] + s
-    __shared__ uint64_t stage[SORT_TILE];
-    const uint32_t wl = blockIdx.y, tile = blockIdx.x;
-    if (threadIdx.x < COARSE_MAX) h[threadIdx.x] = 0;
-    __syncthreads();
-    const uint16_t* d = dig + (size_t)wl * n;
-    const uint32_t base = tile * SORT_TILE;
-    uint32_t codes[SORT_ITEMS];
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
-        codes[k] = i < n ? (uint32_t)d[i] : DIGIT_ZERO;
-        if (codes[k] != DIGIT_ZERO) atomicAdd(&h[(codes[k] & 0x7FFFu) >> fine_bits], 1u);
-    }
-    __syncthreads();
-    // exclusive scan of the (<= 128) bin counts by the first two waves
-    if (threadIdx.x < COARSE_MAX) lstart[threadIdx.x] = threadIdx.x < cb ? h[threadIdx.x] : 0;
-    __syncthreads();
-    for (int dd = 1; dd < COARSE_MAX; dd <<= 1) {
-        uint32_t t = 0;
-        if (threadIdx.x < COARSE_MAX && (int)threadIdx.x >= dd) t = lstart[threadIdx.x - dd];
-        __syncthreads();
-        if (threadIdx.x < COARSE_MAX) lstart[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t incl = 0, cntb = 0;
-    if (threadIdx.x < COARSE_MAX) {
-        incl = lstart[threadIdx.x];
-        cntb = threadIdx.x < cb ? h[threadIdx.x] : 0;
-    }
-    __syncthreads();
-    if (threadIdx.x < COARSE_MAX) {
-        uint32_t excl = incl - cntb;
-        lstart[threadIdx.x] = excl;
-        if (threadIdx.x < cb) delta[threadIdx.x] = Mscan[((size_t)wl * cb + threadIdx.x) * ntile + tile] - excl;   // mod 2^32
-        h[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    const uint32_t total = lstart[cb - 1];   // start of the last bin; its count is added below
-#pragma unroll
-    for (int k = 0; k < SORT_ITEMS; ++k) {
-        if (codes[k] != DIGIT_ZERO) {
-            uint32_t i = base + k * SORT_BLOCK + threadIdx.x;
-            uint32_t b = codes[k] & 0x7FFFu;
-            uint32_t bin = b >> fine_bits;
-            uint32_t fine = b & ((1u << fine_bits) - 1u);
-            uint32_t r = atomicAdd(&h[bin], 1u);
-            uint64_t e = ((uint64_t)bin << 40) | ((uint64_t)fine << 32) | (uint64_t)(i | ((codes[k] & 0x8000u) << 16));
-            stage[lstart[bin] + r] = e;
-        }
-    }
-    __syncthreads();
-    const uint32_t staged = total + h[cb - 1];
-    for (uint32_t s = threadIdx.x; s < staged; s += SORT_BLOCK) {
-        uint64_t e = stage[s];
-        uint32_t bin = (uint32_t)(e >> 40);
-        tmp[(uint32_t)(delta[bin] + s)] = e;
+    for (uint32_t s = threadIdx.x; s < sg.nbins; s += BLOCK) {
+        const uint32_t v = h[s];
+        if (v) atomicAdd(&binhist[s], v);
     }
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK) k_fine_sort(const uint64_t* __restrict__ tmp, const uint32_t* __restrict__ Mscan, uint32_t ntile,
-                                                            uint32_t nbins_total, uint32_t fine_bits, uint32_t cb, uint32_t half,
-                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ count, uint32_t* __restrict__ offset) {
-    // One workgroup per (window, coarse bin).  Sweep 1: histogram of the fine key -> bucket count/offset.
-    // Sweep 2: the bin is walked in tiles of SORT_TILE entries; each tile is counting-sorted in LDS and
-    // every (tile, bucket) run is then stored by consecutive lanes, so the writes into `sorted` are
-    // coalesced runs instead of 4-byte scatters (which cost 6x write amplification, profiles/r01_pmc_*).
-    __shared__ uint32_t h[256];        // bucket populations of the whole bin
-    __shared__ uint32_t lofs[256];     // bucket start inside the bin, advanced tile by tile
-    __shared__ uint32_t th[256];       // tile: counts, then cursors
-    __shared__ uint32_t tstart[256];   // tile: start of each bucket inside the staged tile
-    __shared__ uint32_t delta[256];    // global position of staged slot s = delta[bucket] + s
-    __shared__ uint64_t stage[SORT_TILE];
-    const uint32_t bin = blockIdx.x;                          // = wl * cb + coarse bin
-    const uint32_t start = Mscan[(size_t)bin * ntile];
-    const uint32_t end = Mscan[(size_t)(bin + 1) * ntile];    // the scan carries one extra element = total
-    const uint32_t nf = 1u << fine_bits;
+// single workgroup: binstart[k] = exclusive scan of binhist (binstart[nbins] = total), cursor[k] = binstart[k]
+__global__ void __launch_bounds__(1024) k_bin_scan(const uint32_t* __restrict__ binhist, uint32_t nbins, uint32_t* __restrict__ binstart,
+                                                    uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
     const uint32_t t = threadIdx.x;
-    h[t] = 0;
+    if (t == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t p = start + t; p < end; p += SORT_BLOCK) atomicAdd(&h[(uint32_t)(tmp[p] >> 32) & 0xFFu], 1u);
-    __syncthreads();
-    uint32_t v = h[t];
-    lofs[t] = v;
-    __syncthreads();
-    for (int dd = 1; dd < 256; dd <<= 1) {
-        uint32_t x = (int)t >= dd ? lofs[t - dd] : 0;
-        __syncthreads();
-        lofs[t] += x;
-        __syncthreads();
-    }
-    uint32_t excl = lofs[t] - v;
-    __syncthreads();
-    lofs[t] = excl;
-    if (t < nf) {
-        uint32_t wl = bin / cb, cbin = bin % cb;
-        uint32_t gb = wl * half + (cbin << fine_bits) + t;
-        count[gb] = v;
-        offset[gb] = start + excl;
-    }
-    __syncthreads();
-    for (uint32_t tb = start; tb < end; tb += SORT_TILE) {
-        const uint32_t tn = min((uint32_t)SORT_TILE, end - tb);
-        th[t] = 0;
-        __syncthreads();
-        uint64_t e[SORT_ITEMS];
+    for (uint32_t base = 0; base < nbins; base += 1024) {
+        const uint32_t i = base + t;
+        const uint32_t v = i < nbins ? binhist[i] : 0u;
+        uint32_t incl = v;
 #pragma unroll
-        for (int k = 0; k < SORT_ITEMS; ++k) {
-            uint32_t s = k * SORT_BLOCK + t;
-            e[k] = s < tn ? tmp[tb + s] : ~0ull;
-            if (s < tn) atomicAdd(&th[(uint32_t)(e[k] >> 32) & 0xFFu], 1u);
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if ((int)(t & 63u) >= d) incl += o;
+        }
+        if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+        __syncthreads();
+        uint32_t run = carry_s + incl - v;
+        for (uint32_t q = 0; q < (t >> 6); ++q) run += wsum[q];
+        if (i < nbins) {
+            binstart[i] = run;
+            cursor[i] = run;
         }
         __syncthreads();
-        uint32_t c = th[t];
-        tstart[t] = c;
+        if (t == 1023) carry_s = run + v;
         __syncthreads();
-        for (int dd = 1; dd < 256; dd <<= 1) {
-            uint32_t x = (int)t >= dd ? tstart[t - dd] : 0;
-            __syncthreads();
-            tstart[t] += x;
-            __syncthreads();
+    }
+    if (t == 0) binstart[nbins] = carry_s;
+}
+
+// partition entry
+template <class E>
+MSM_D E make_entry(uint32_t idx, bool neg, uint32_t fine, uint32_t idxbits);
+template <>
+MSM_D uint32_t make_entry<uint32_t>(uint32_t idx, bool neg, uint32_t fine, uint32_t idxbits) {
+    return idx | ((neg ? 1u : 0u) << idxbits) | (fine << (idxbits + 1));
+}
+template <>
+MSM_D uint2 make_entry<uint2>(uint32_t idx, bool neg, uint32_t fine, uint32_t) {
+    return make_uint2(idx | (neg ? 0x80000000u : 0u), fine);
+}
+MSM_D uint32_t entry_fine(uint32_t e, uint32_t idxbits) { return e >> (idxbits + 1); }
+MSM_D uint32_t entry_fine(uint2 e, uint32_t) { return e.y; }
+// index with the sign in bit 31: what the accumulation kernels read
+MSM_D uint32_t entry_sorted(uint32_t e, uint32_t idxbits) { return (e & ((1u << idxbits) - 1u)) | (((e >> idxbits) & 1u) << 31); }
+MSM_D uint32_t entry_sorted(uint2 e, uint32_t) { return e.x; }
+
+// block-wide exclusive scan of nf counters in LDS, in place; returns their sum.  Lane t owns the consecutive counters
+// [t*per, (t+1)*per), per = ceil(nf / BLOCK).  wsum: BLOCK / 64 words of LDS.
+template <int BLOCK = SORT_BLOCK>
+MSM_D uint32_t block_exclusive_scan(uint32_t* a, uint32_t nf, uint32_t* wsum) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nf + BLOCK - 1) / BLOCK;
+    uint32_t s = 0;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t i = t * per + j;
+        if (i < nf) s += a[i];
+    }
+    uint32_t incl = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(t & 63u) >= d) incl += o;
+    }
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - s, total = 0;
+#pragma unroll
+    for (int q = 0; q < BLOCK / 64; ++q) {
+        if (q < (int)(t >> 6)) run += wsum[q];
+        total += wsum[q];
+    }
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t i = t * per + j;
+        if (i < nf) {
+            const uint32_t v = a[i];
+            a[i] = run;
+            run += v;
         }
-        uint32_t ts = tstart[t] - c;
-        __syncthreads();
-        tstart[t] = ts;
-        delta[t] = start + lofs[t] - ts;   // mod 2^32
-        lofs[t] += c;                      // next tile of this bucket continues here
-        th[t] = 0;
+    }
+    __syncthreads();
+    return total;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_tile_scatter: the tile's entries of GW windows at a time are counting-sorted by (window, coarse bin) in LDS -- the rank of an
+// entry inside its run comes back from the LDS histogram's atomic -- every non-empty run reserves its place in the bin with ONE
+// global atomic on the bin's cursor, and the staged runs are stored by consecutive lanes (a run of a 4096-item tile is ~32 entries,
+// one 128-byte line).  Storing every entry straight from its lane instead (no staging) was measured: 64 separate 4-byte requests
+// per wave instruction, 90 us against 50 for the whole kernel (profiles/r02_sort_variants.txt).  The order of the tiles inside a
+// bin is whatever order the reservations arrive in: sums do not care.
+// ------------------------------------------------------------------------------------------
+template <int NW, int ITEMS, int BLOCK, class E, int GW>
+__global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ cursor,
+                                                         E* __restrict__ tmp) {
+    constexpr int T = ITEMS * BLOCK;
+    static_assert(T <= 4096, "ranks are packed into 12 bits");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
+    E* stage = reinterpret_cast<E*>(smem_raw);                                  // [GW * T] entries grouped by run
+    uint32_t* hs = reinterpret_cast<uint32_t*>(stage + GW * T);                 // [GW * cb] counts, then the start of each run in `stage`
+    uint32_t* gb = hs + GW * COARSE_MAX;                                        // [GW * cb] where the run goes in tmp
+    uint32_t* wsum = gb + GW * COARSE_MAX;                                      // [BLOCK / 64]
+    uint16_t* srun = reinterpret_cast<uint16_t*>(wsum + BLOCK / 64);            // [GW * T] run of every staged entry
+    const uint32_t tile = blockIdx.x, t = threadIdx.x;
+    DigitSource<NW, ITEMS, BLOCK> ds;
+    ds.load(scalars, g, tile * T);
+    const uint32_t ncnt = GW * sg.cb;
+    for (uint32_t w0 = 0; w0 < g.W; w0 += GW) {
+        uint32_t mr[GW][ITEMS];   // magnitude (<= 2^20) << 12 | rank inside the run
+        uint32_t negm[GW];
+        bool any = false;
+        for (uint32_t s = t; s < ncnt; s += BLOCK) hs[s] = 0;
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < SORT_ITEMS; ++k) {
-            uint32_t s = k * SORT_BLOCK + t;
-            if (s < tn) {
-                uint32_t f = (uint32_t)(e[k] >> 32) & 0xFFu;
-                uint32_t r = atomicAdd(&th[f], 1u);
-                stage[tstart[f] + r] = e[k];
+        for (int gw = 0; gw < GW; ++gw) {
+            const uint32_t w = w0 + gw;
+            const bool owned = w < g.W && (w % g.nshards) == g.shard;
+            any |= owned;
+            negm[gw] = 0;
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                mr[gw][k] = 0;
+                if (w < g.W) {
+                    uint32_t mag;
+                    bool neg;
+                    ds.next(scalars, g, k, w, mag, neg);
+                    if (neg) negm[gw] |= 1u << k;
+                    if (owned && mag != 0) mr[gw][k] = (mag << 12) | atomicAdd(&hs[gw * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
+                }
             }
         }
         __syncthreads();
-        for (uint32_t s = t; s < tn; s += SORT_BLOCK) {
-            uint64_t x = stage[s];
-            uint32_t f = (uint32_t)(x >> 32) & 0xFFu;
-            sorted[(uint32_t)(delta[f] + s)] = (uint32_t)x;
+        if (!any) continue;   // uniform over the workgroup (the next iteration's clearing is behind its own barrier)
+        // every non-empty run reserves its span of the bin
+        for (uint32_t s = t; s < ncnt; s += BLOCK) {
+            const uint32_t w = w0 + s / sg.cb, bin = s % sg.cb, cnt = hs[s];
+            gb[s] = cnt ? atomicAdd(&cursor[(w / g.nshards) * sg.cb + bin], cnt) : 0u;   // cnt != 0 only for owned windows
+        }
+        const uint32_t staged = block_exclusive_scan<BLOCK>(hs, ncnt, wsum);   // hs: start of each run inside the staged group
+#pragma unroll
+        for (int gw = 0; gw < GW; ++gw) {
+#pragma unroll
+            for (int k = 0; k < ITEMS; ++k) {
+                if (mr[gw][k] != 0) {
+                    const uint32_t b = (mr[gw][k] >> 12) - 1, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
+                    stage[slot] = make_entry<E>(ds.first + k * BLOCK, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
+                    srun[slot] = (uint16_t)run;
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = t; s < staged; s += BLOCK) {
+            const uint32_t run = srun[s];
+            tmp[gb[run] + (s - hs[run])] = stage[s];
         }
         __syncthreads();
     }
-    (void)nbins_total;
+}
+// dynamic LDS of k_tile_scatter
+template <class E>
+constexpr size_t tile_scatter_lds(int T, int GW, int BLOCK) {
+    return (size_t)GW * T * sizeof(E) + (size_t)2 * GW * COARSE_MAX * 4 + (size_t)(BLOCK / 64) * 4 + (size_t)GW * T * 2;
 }
 
 // ------------------------------------------------------------------------------------------
-// stage 2: exclusive scan of bucket populations (three small kernels) and ordering by population
+// fine sort of one (window, coarse bin) span: bucket count / offset tables and the index lists grouped by bucket
 // ------------------------------------------------------------------------------------------
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 16;                       // per thread
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;   // 4096 per workgroup
+constexpr int FINE_ITEMS = 36;                         // entries per lane held in registers
+constexpr int FINE_CAP = FINE_ITEMS * SORT_BLOCK;      // 9216: spans up to this size are read once by one workgroup
 
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tile_sums(const uint32_t* __restrict__ count, uint32_t nb, uint32_t* __restrict__ tile_sums) {
-    __shared__ uint32_t red[SCAN_BLOCK];
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < nb) s += count[base + k];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int d = SCAN_BLOCK / 2; d > 0; d >>= 1) {
-        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = red[0];
-}
-// single workgroup: in-place exclusive scan of the tile sums
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_tiles(uint32_t* __restrict__ tile_sums, uint32_t ntiles) {
-    __shared__ uint32_t buf[SCAN_BLOCK];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t start = 0; start < ntiles; start += SCAN_BLOCK) {
-        uint32_t idx = start + threadIdx.x;
-        uint32_t v = idx < ntiles ? tile_sums[idx] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
-            uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+// LONG_HERE: spans beyond FINE_CAP are handled by this workgroup too (chunk by chunk: histogram sweep, then chunk-wise counting
+// sort with stores by bucket runs) -- the form launched when no long span is expected, so that an unexpected one (adversarial
+// scalars at small n) is still sorted correctly, just by a single workgroup.  Otherwise they are left to the k_big_* kernels.
+template <class E, bool LONG_HERE>
+__global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half,
+                                                            uint32_t* __restrict__ sorted, uint32_t* __restrict__ count, uint32_t* __restrict__ offset) {
+    extern __shared__ uint32_t smem_u32[];
+    const uint32_t nf = 1u << sg.fbits;
+    uint32_t* h = smem_u32;                 // [nf]   bucket populations, then exclusive starts
+    uint32_t* out = smem_u32 + 2 * nf;      // [FINE_CAP] the span (or one chunk of it), grouped by bucket
+    __shared__ uint32_t wsum[SORT_BLOCK / 64];
+    const uint32_t bin = blockIdx.x;                              // = wl * cb + coarse bin
+    const uint32_t start = binstart[bin], end = binstart[bin + 1];
+    const uint32_t span = end - start, t = threadIdx.x;
+    const uint32_t wl = bin / sg.cb, cbin = bin % sg.cb;
+    const uint32_t gb0 = wl * half + (cbin << sg.fbits);
+    if (span > (uint32_t)FINE_CAP) {
+        if constexpr (LONG_HERE) {
+            uint32_t* th = smem_u32 + nf;   // [nf] chunk: counts, then exclusive starts inside the chunk
+            for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
             __syncthreads();
-            buf[threadIdx.x] += t;
+            for (uint32_t p = start + t; p < end; p += SORT_BLOCK) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
             __syncthreads();
+            for (uint32_t i = t; i < nf; i += SORT_BLOCK) count[gb0 + i] = h[i];
+            __syncthreads();
+            block_exclusive_scan(h, nf, wsum);
+            for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
+            // h[f]: next free position of bucket f relative to `start`
+            for (uint32_t cbeg = start; cbeg < end; cbeg += FINE_CAP) {
+                const uint32_t cn = min((uint32_t)FINE_CAP, end - cbeg);
+                for (uint32_t i = t; i < nf; i += SORT_BLOCK) th[i] = 0;
+                __syncthreads();
+                for (uint32_t s = t; s < cn; s += SORT_BLOCK) {
+                    const E e = tmp[cbeg + s];
+                    const uint32_t f = entry_fine(e, sg.idxbits);
+                    const uint32_t r = atomicAdd(&th[f], 1u);
+                    sorted[start + h[f] + r] = entry_sorted(e, sg.idxbits);   // h is not modified during this loop
+                }
+                __syncthreads();
+                for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] += th[i];
+                __syncthreads();
+            }
         }
-        uint32_t incl = buf[threadIdx.x];
-        if (idx < ntiles) tile_sums[idx] = carry + incl - v;
+        return;
+    }
+    for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
+    __syncthreads();
+    E e[FINE_ITEMS];
+    uint32_t rank[FINE_ITEMS];
+#pragma unroll
+    for (int k = 0; k < FINE_ITEMS; ++k) {
+        const uint32_t s = k * SORT_BLOCK + t;
+        if (s < span) e[k] = tmp[start + s];
+    }
+#pragma unroll
+    for (int k = 0; k < FINE_ITEMS; ++k) {
+        const uint32_t s = k * SORT_BLOCK + t;
+        if (s < span) rank[k] = atomicAdd(&h[entry_fine(e[k], sg.idxbits)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < nf; i += SORT_BLOCK) count[gb0 + i] = h[i];
+    __syncthreads();
+    block_exclusive_scan(h, nf, wsum);
+    for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
+#pragma unroll
+    for (int k = 0; k < FINE_ITEMS; ++k) {
+        const uint32_t s = k * SORT_BLOCK + t;
+        if (s < span) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits);
+    }
+    __syncthreads();
+    for (uint32_t s = t; s < span; s += SORT_BLOCK) sorted[start + s] = out[s];
+}
+
+// ---- spans beyond FINE_CAP (large n; the few dense bins of a partly used top window; adversarial scalars): cut into chunks of
+// BIG_CHUNK entries that workgroups process in parallel.
+//   k_big_plan     chunks per bin and their exclusive scan
+//   k_big_desc     chunk list: desc[i] = (bin, first entry of the chunk)
+//   k_big_hist     per chunk: LDS histogram of the fine key -> global bucket counts (one atomic per non-empty (chunk, bucket))
+//   k_big_offsets  per big bin: offsets = bin start + exclusive scan of its bucket counts; cursors start there
+//   k_big_scatter  per chunk: LDS counting sort, every (chunk, bucket) run reserves its place with one atomic on the bucket's
+//                  cursor and is stored by consecutive lanes
+constexpr int BIG_ITEMS = 32;
+constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries
+
+__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t* __restrict__ cpre) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nbins; base += 1024) {
+        const uint32_t i = base + t;
+        uint32_t v = 0;
+        if (i < nbins) {
+            const uint32_t span = binstart[i + 1] - binstart[i];
+            v = span > (uint32_t)FINE_CAP ? (span + BIG_CHUNK - 1) / BIG_CHUNK : 0u;
+        }
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t o = __shfl_up(incl, d, 64);
+            if ((int)(t & 63u) >= d) incl += o;
+        }
+        if ((t & 63u) == 63u) wsum[t >> 6] = incl;
         __syncthreads();
-        if (threadIdx.x == SCAN_BLOCK - 1) carry += incl;
+        uint32_t run = carry_s + incl - v;
+        for (uint32_t q = 0; q < (t >> 6); ++q) run += wsum[q];
+        if (i < nbins) cpre[i] = run;
+        __syncthreads();
+        if (t == 1023) carry_s = run + v;
+        __syncthreads();
+    }
+    if (t == 0) cpre[nbins] = carry_s;
+}
+__global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre, uint32_t nbins,
+                                                   uint2* __restrict__ desc) {
+    const uint32_t total = cpre[nbins];
+    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = nbins;   // largest bin with cpre[bin] <= it (bins without chunks repeat the value: take the last)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cpre[mid] <= it) lo = mid;
+            else hi = mid;
+        }
+        desc[it] = make_uint2(lo, binstart[lo] + (it - cpre[lo]) * BIG_CHUNK);
+    }
+}
+template <class E>
+__global__ void __launch_bounds__(SORT_BLOCK) k_big_hist(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
+                                                          const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t* __restrict__ count) {
+    extern __shared__ uint32_t smem_u32[];
+    uint32_t* h = smem_u32;   // [nf]
+    const uint32_t nf = 1u << sg.fbits, total = cpre[sg.nbins], t = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const uint2 d = desc[it];
+        const uint32_t end = min(binstart[d.x + 1], d.y + BIG_CHUNK);
+        for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
+        __syncthreads();
+        for (uint32_t p = d.y + t; p < end; p += SORT_BLOCK) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
+        __syncthreads();
+        const uint32_t gb0 = (d.x / sg.cb) * half + ((d.x % sg.cb) << sg.fbits);
+        for (uint32_t i = t; i < nf; i += SORT_BLOCK) {
+            const uint32_t v = h[i];
+            if (v) atomicAdd(&count[gb0 + i], v);
+        }
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const uint32_t* __restrict__ count, uint32_t nb, const uint32_t* __restrict__ tile_sums,
-                                                            uint32_t* __restrict__ offset, uint32_t* __restrict__ cursor) {
-    __shared__ uint32_t buf[SCAN_BLOCK];
-    uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t loc[SCAN_ITEMS];
-    uint32_t s = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        loc[k] = (base + k < nb) ? count[base + k] : 0;
-        s += loc[k];
-    }
-    buf[threadIdx.x] = s;
+__global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half, const uint32_t* __restrict__ count,
+                                                             uint32_t* __restrict__ offset, uint32_t* __restrict__ bcursor) {
+    extern __shared__ uint32_t smem_u32[];
+    uint32_t* h = smem_u32;   // [nf]
+    __shared__ uint32_t wsum[SORT_BLOCK / 64];
+    const uint32_t bin = blockIdx.x, start = binstart[bin], t = threadIdx.x, nf = 1u << sg.fbits;
+    if (binstart[bin + 1] - start <= (uint32_t)FINE_CAP) return;
+    const uint32_t gb0 = (bin / sg.cb) * half + ((bin % sg.cb) << sg.fbits);
+    for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = count[gb0 + i];
     __syncthreads();
-    for (int d = 1; d < SCAN_BLOCK; d <<= 1) {
-        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
-        __syncthreads();
-        buf[threadIdx.x] += t;
-        __syncthreads();
+    block_exclusive_scan(h, nf, wsum);
+    for (uint32_t i = t; i < nf; i += SORT_BLOCK) {
+        offset[gb0 + i] = start + h[i];
+        bcursor[gb0 + i] = start + h[i];
     }
-    uint32_t run = tile_sums[blockIdx.x] + buf[threadIdx.x] - s;
+}
+template <class E>
+__global__ void __launch_bounds__(SORT_BLOCK) k_big_scatter(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
+                                                             const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t* __restrict__ bcursor,
+                                                             uint32_t* __restrict__ sorted) {
+    extern __shared__ uint32_t smem_u32[];
+    const uint32_t nf = 1u << sg.fbits;
+    uint32_t* th = smem_u32;                // [nf] chunk: counts, then exclusive starts inside the staged chunk
+    uint32_t* gb = smem_u32 + nf;           // [nf] global position of the chunk's run of each bucket
+    uint32_t* stage = smem_u32 + 2 * nf;    // [BIG_CHUNK]
+    uint32_t* spos = stage + BIG_CHUNK;     // [BIG_CHUNK]
+    __shared__ uint32_t wsum[SORT_BLOCK / 64];
+    const uint32_t total = cpre[sg.nbins], t = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+        const uint2 d = desc[it];
+        const uint32_t cn = min(binstart[d.x + 1], d.y + BIG_CHUNK) - d.y;
+        const uint32_t gb0 = (d.x / sg.cb) * half + ((d.x % sg.cb) << sg.fbits);
+        for (uint32_t i = t; i < nf; i += SORT_BLOCK) th[i] = 0;
+        __syncthreads();
+        E e[BIG_ITEMS];
+        uint32_t rank[BIG_ITEMS];
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k) {
-        if (base + k < nb) {
-            offset[base + k] = run;
-            cursor[base + k] = run;
+        for (int k = 0; k < BIG_ITEMS; ++k) {
+            const uint32_t s = k * SORT_BLOCK + t;
+            if (s < cn) e[k] = tmp[d.y + s];
         }
-        run += loc[k];
+#pragma unroll
+        for (int k = 0; k < BIG_ITEMS; ++k) {
+            const uint32_t s = k * SORT_BLOCK + t;
+            if (s < cn) rank[k] = atomicAdd(&th[entry_fine(e[k], sg.idxbits)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < nf; i += SORT_BLOCK) {
+            const uint32_t v = th[i];
+            gb[i] = v ? atomicAdd(&bcursor[gb0 + i], v) : 0u;
+        }
+        __syncthreads();
+        block_exclusive_scan(th, nf, wsum);
+#pragma unroll
+        for (int k = 0; k < BIG_ITEMS; ++k) {
+            const uint32_t s = k * SORT_BLOCK + t;
+            if (s < cn) {
+                const uint32_t f = entry_fine(e[k], sg.idxbits), slot = th[f] + rank[k];
+                stage[slot] = entry_sorted(e[k], sg.idxbits);
+                spos[slot] = gb[f] + rank[k];
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = t; s < cn; s += SORT_BLOCK) sorted[spos[s]] = stage[s];
+        __syncthreads();
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// ordering of the buckets by population
+// ------------------------------------------------------------------------------------------
 // Ordering of buckets by population (descending), counting sort on min(count, ORDER_BINS-1).
 constexpr int ORDER_BINS = 1024;
 // Sort key: (bucket >= split ? 1 : 0, size class).  With split < nb the order array comes out as
