@@ -75,7 +75,7 @@ const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
 /* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
  * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
- * "sort_atomic" (1 = global-atomic scatter instead of the LDS radix partition), "slots" (calls in flight, 1..8),
+ * "sort_big" (fine sort of long spans: 0 = chunk-parallel kernels where long spans are expected, 1 = always, 2 = never), "slots" (calls in flight, 1..8),
  * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default),
  * "glv" (0 never | 1 (default) where it pays AND the call carries MSM_AMD_BASES_IN_SUBGROUP | 2 whenever it applies, the option itself
  * being the caller's word that the bases lie in the order-r subgroup: the GLV schedule of BLS12-381 G1),
@@ -119,6 +119,28 @@ int msm_amd_multiexp_shard_async(msm_amd_ctx *ctx, int curve, int group, uint32_
                                  uint32_t nshards, uint64_t *ticket);
 /* out = normalise(sum of `count` Jacobian partials) -- host only, no GPU needed */
 int msm_amd_combine(int curve, int group, const uint8_t *partials, uint32_t count, uint8_t *out);
+
+/* ---- multi-GPU: the exchange itself, RCCL over xGMI behind the C ABI (one process per GPU) ------------------------------
+ * The reference's seam is its per-window export fnName_chunk (build_multiexp.js:96-104, :469), which its external caller fans out
+ * to workers and recombines on the main thread; here the workers are the GPUs of one node.
+ *   rank 0:      msm_amd_dist_unique_id(id)           -> 128 bytes, handed to the other ranks by whatever channel the host has
+ *   every rank:  msm_amd_dist_init(ctx, rank, world, id)   (collective: returns when all ranks have joined)
+ *                msm_amd_multiexp_dist(ctx, ...)      -> this rank's windows on this rank's GPU, ONE ncclAllGather of
+ *                                                        world x (144 | 96 | 288 | 192) bytes, the partials added on the host:
+ *                                                        the same normalised result on every rank
+ *                msm_amd_dist_destroy(ctx)            (also done by msm_amd_destroy)
+ * The asynchronous pair keeps several sharded calls in flight per rank (up to `slots`); every rank must collect its tickets in
+ * the same order.  RCCL is dlopen'ed on first use.  With more than four ranks export GPU_MAX_HW_QUEUES=8 before the process
+ * starts (read by the HIP runtime at start-up; msm_amd_dist_init warns when it is missing).                                    */
+int msm_amd_dist_unique_id(uint8_t *out128);
+int msm_amd_dist_init(msm_amd_ctx *ctx, int rank, int world, const uint8_t *id128);
+int msm_amd_dist_destroy(msm_amd_ctx *ctx);
+int msm_amd_dist_info(const msm_amd_ctx *ctx, int *rank, int *world); /* world = 0: not in a group */
+int msm_amd_multiexp_dist(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, const void *scalars,
+                          uint32_t scalar_size, uint32_t n, uint8_t *out);
+int msm_amd_multiexp_dist_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
+                                const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);
+int msm_amd_dist_wait(msm_amd_ctx *ctx, int curve, int group, uint64_t ticket, uint8_t *out);
 
 /* ---- reference-named wrappers (host pointers) ------------------------------------------------- */
 #define MSM_AMD_DECL(curve, g)                                                                                       \

@@ -131,6 +131,68 @@ def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     assert C.g1m_multiexpAffine(good, gs, 32, n) == expg
 
 
+@pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 2)])
+def test_wide_windows_and_both_forms_of_the_fine_sort(eng, orc, curve, group):
+    """Windows wider than 16 bits (8 coarse + up to 12 fine bits of bucket index, 8-byte partition entries are not needed at this n)
+    and the two forms of the fine sort -- one workgroup per span, or long spans cut into chunks sorted in parallel (option
+    "sort_big": 1 = always the chunk-parallel kernels, 2 = never) -- all give the oracle's bytes.  n = 12000 with 9-bit windows
+    makes every span long (12000 / 1 coarse bin), with 17..21-bit windows the spans are short and mostly empty."""
+    n = 12000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, scalars = gu.random_case(curve, group, f"gpu:wide:{curve}:{group}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    f = getattr(C, f"g{group}m_multiexpAffine")
+    try:
+        for c in (9, 17, 19, 21):
+            eng.set_window_bits(c)
+            for big in (1, 2, 0):
+                eng.set_option("sort_big", big)
+                assert f(bases, scalars, 32, n) == exp, (c, big)
+                assert eng.geometry()["c"] == c
+        # a window shard and a _chunk call on the wide path
+        eng.set_window_bits(18)
+        import msm_amd
+        parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, r, 3) for r in range(3))
+        assert msm_amd.combine(curve, group, parts) == exp
+    finally:
+        eng.set_window_bits(0)
+        eng.set_option("sort_big", 0)
+
+
+def test_all_equal_scalars_take_the_long_span_paths(eng, orc):
+    """Adversarial scalars (all equal: one bucket per window receives every point) at a size where that bucket's span is far beyond
+    what one workgroup reads at once: the chunk-parallel sort, the single-workgroup fallback and the segmented accumulation of
+    over-long buckets all have to agree with n * (k * P) computed by the oracle."""
+    curve, group, n = "bls12381", 1, 50000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, _ = gu.random_case(curve, group, "gpu:alleq", 16)
+    k = (0x1234567890abcdef1122334455667788 << 96 | 0x8000_0000_7fff_8001).to_bytes(32, "little")
+    scalars = k * n
+    big_bases = (bases * (n // 16 + 1))[:96 * n]
+    # sum_i k * P_(i mod 16) = k * (n/16 * sum of the 16 points) + remainder: let the oracle do it on the 16 distinct points
+    cnt = [n // 16 + (1 if i < n % 16 else 0) for i in range(16)]
+    sc16 = b"".join(((int.from_bytes(k, "little") * c) % gu.R_ORDER[curve]).to_bytes(32, "little") for c in cnt)
+    exp = O.normalize(O.multiexp_affine(bases, sc16, 32, 16))
+    try:
+        for big in (1, 2, 0):
+            eng.set_option("sort_big", big)
+            assert C.g1m_multiexpAffine(big_bases, scalars, 32, n) == exp, big
+    finally:
+        eng.set_option("sort_big", 0)
+
+
+def test_reduce_l_must_be_a_power_of_two(eng):
+    """The LDS trees of the bucket reduction halve the lane count: a lane count that is not a power of two would drop a partial
+    sum (reduce_l = 200 at c = 16 gave 164 lanes).  The option refuses such values instead."""
+    import msm_amd
+    with pytest.raises(msm_amd.MsmAmdError, match="power of two"):
+        eng.set_option("reduce_l", 200)
+    eng.set_option("reduce_l", 64)
+    eng.set_option("reduce_l", 0)
+
+
 def test_entries_of_one_pass_must_fit_32_bits(eng):
     """windows x points >= 2^32 would wrap the 32-bit positions of the sort: refused, not computed wrongly.  One-bit windows over
     256-bit scalars are 257 windows; 2^24 points x 257 > 2^32.  (Buffers are uninitialised: the call is refused before any kernel.)"""
@@ -165,6 +227,85 @@ def test_bench_gpus_2_reports_two_ranks():
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
     assert "sharded over 2" in line["config"]["parallelism"]
+
+
+def test_dist_entry_points_with_a_group_of_one(orc):
+    """The exchange behind the C ABI (msm_amd_dist_init / msm_amd_multiexp_dist[_async] / msm_amd_dist_wait: RCCL communicator,
+    ncclAllGather of the partial, host combine) with the one rank a one-GPU box can hold."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 3000
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, "gpu:dist1", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        with pytest.raises(msm_amd.MsmAmdError, match="dist_init"):
+            C.multiexp_dist(group, bases, scalars, 32, n)
+        eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        assert C.multiexp_dist(group, bases, scalars, 32, n) == exp
+        t1 = C.multiexp_dist_async(group, bases, scalars, 32, n)
+        t2 = C.multiexp_dist_async(group, bases, scalars, 32, n)
+        assert t1.wait() == exp and t2.wait() == exp
+        with pytest.raises(msm_amd.MsmAmdError, match="already"):
+            eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        eng.dist_destroy()
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp      # the context is an ordinary one again
+    finally:
+        eng.close()
+
+
+def _cabi_dist_rank(rank, world, q_id, q):
+    for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "zprize-wasm-msm_amd", "python")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import msm_amd
+    from oracle import oracle as orcm
+    eng = msm_amd.Engine(rank)
+    try:
+        if rank == 0:
+            uid = msm_amd.dist_unique_id()
+            for _ in range(world - 1):
+                q_id.put(uid)
+        else:
+            uid = q_id.get(timeout=300)
+        eng.dist_init(rank, world, uid)
+        curve, group, n = "bn128", 1, 6000
+        C = eng.curve(curve)
+        bases, scalars = gu.random_case(curve, group, "gpu:cabi-dist", n)
+        d_b = eng.alloc(len(bases)).upload(bases)
+        d_s = eng.alloc(len(scalars)).upload(scalars)
+        r1 = C.multiexp_dist(group, d_b, d_s, 32, n)
+        t = [C.multiexp_dist_async(group, d_b, d_s, 32, n) for _ in range(2)]
+        r2, r3 = t[0].wait(), t[1].wait()
+        ok = r1 == r2 == r3
+        if rank == 0:
+            orcm.build()
+            O = orcm.Oracle(curve, group)
+            ok = ok and r1 == O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        q.put((rank, ok, r1.hex()[:16]))
+    finally:
+        eng.close()
+
+
+def test_two_ranks_through_the_c_entry_points():
+    """The same two-GPU exchange with nothing but the C ABI in the data path: msm_amd_dist_unique_id on rank 0, msm_amd_dist_init on
+    both, msm_amd_multiexp_dist[_async] -- what a Node host reaches through the addon's distInit / multiexpDist."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q, q_id = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_cabi_dist_rank, args=(r, 2, q_id, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert len({h for _, _, h in res}) == 1
 
 
 def _rccl_rank(rank, world, port, q):

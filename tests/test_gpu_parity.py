@@ -224,7 +224,7 @@ def test_randomised_configurations(eng, orc):
             scalars = gu.stream(f"gpu:rand:{it}:s", n * ss)
             eng.set_window_bits(rnd.choice([0, 0, 1, 3, 4, 7, 11, 16]))
             eng.set_option("segment", rnd.choice([0, 0, 1, 2, 5, 64]))
-            eng.set_option("reduce_l", rnd.choice([0, 0, 1, 3, 16]))
+            eng.set_option("reduce_l", rnd.choice([0, 0, 1, 2, 16]))
             eng.set_option("split", rnd.choice([0, 1]))
             mode = rnd.choice(["full", "full", "chunk", "shard"])
             if mode == "full":

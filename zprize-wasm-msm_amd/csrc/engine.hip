@@ -452,8 +452,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     };
     auto plan = [&](uint32_t nbuckets) {
         Plan p;
-        p.L = others_pending ? std::min(32u, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
-                             : std::min(8u * lanes_per_point<FK>(), std::max(1u, (nbuckets * lanes_per_point<FK>() + 65535u) / 65536u));
+        // (wide windows have 16-32 times the buckets: with 2^19 per window even a lone call fills the chip many times over at
+        // L = 8, and what counts is again the instruction volume -- n = 2^24, c = 20: reduction 8.6 ms at L = 8, 4.6 at L = 128,
+        // profiles/r02_reduce_l_wide_windows.txt -- hence the same rule with a cap of 128 instead of a fixed 8)
+        const uint32_t wide_cap = g.c > 16 ? 128u : (others_pending ? 32u : 8u);
+        p.L = others_pending ? std::min(wide_cap, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
+                             : std::min(wide_cap * lanes_per_point<FK>(), std::max(1u, (uint32_t)(((uint64_t)nbuckets * lanes_per_point<FK>() + 65535u) / 65536u)));
         // a power of two (the nearer one): a lane multiplies its run by its first index t*L with double-and-add, and the zero low
         // bits of that index cost no additions (sharded calls: L = 10 -> 8 took 1.25 -> 1.17 ms per call at 4 ranks, 18 -> 16 1.62 -> 1.56 at 2)
         {
@@ -461,7 +465,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             while (f * 2 <= p.L) f *= 2;
             p.L = (2 * p.L >= 3 * f) ? 2 * f : f;
         }
-        if (ctx->force_L) p.L = ctx->force_L;
+        if (ctx->force_L) p.L = ctx->force_L;   // (a power of two: msm_amd_set_option rejects anything else -- the LDS trees halve)
         p.lanes = (g.half + p.L - 1) / p.L;
         p.rblock = std::min(256u, std::max(64u, p.lanes));
         while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
@@ -835,7 +839,10 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     msm_amd_ctx* ctx = new (std::nothrow) msm_amd_ctx();
     if (!ctx) return MSM_AMD_ENOMEM;
     ctx->device = device_id;
-    if (const char* e = getenv("MSM_AMD_REDUCE_L")) ctx->force_L = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_REDUCE_L")) {
+        const uint32_t v = (uint32_t)atoi(e);
+        if ((v & (v - 1)) == 0) ctx->force_L = v;   // powers of two only (see msm_amd_set_option "reduce_l")
+    }
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -862,6 +869,7 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
 
 void msm_amd_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return;
+    (void)msm_amd_dist_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream_s) (void)hipStreamSynchronize(ctx->stream_s);
     if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
@@ -931,7 +939,13 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!ctx || !name) return MSM_AMD_EINVAL;
     if (!strcmp(name, "window_bits")) return msm_amd_set_window_bits(ctx, value);
     if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
-    if (!strcmp(name, "reduce_l")) { ctx->force_L = value; return 0; }
+    if (!strcmp(name, "reduce_l")) {
+        // lanes per workgroup follow from L (rblock = min(256, max(64, buckets / L))) and the workgroup's LDS tree halves: a value that is
+        // not a power of two would give an odd lane count somewhere on the way down and drop a partial sum
+        if (value & (value - 1)) { msm_set_err(ctx, "reduce_l must be 0 (automatic) or a power of two"); return MSM_AMD_EINVAL; }
+        ctx->force_L = value;
+        return 0;
+    }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "sort_big")) { ctx->sort_big = value > 2 ? 0 : (int)value; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }

@@ -56,8 +56,22 @@ struct Slot {
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
 
+struct msm_nccl_id {   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
+    char internal[128];
+};
+
 struct msm_amd_ctx {
     int device = 0;
+    // multi-GPU group this context belongs to (dist.hip): RCCL communicator + staging for the exchange of the window partials
+    struct Dist {
+        void* comm = nullptr;
+        int rank = 0, world = 0;
+        void* d_buf = nullptr;
+        void* h_buf = nullptr;   // pinned
+        hipStream_t stream = nullptr;
+        size_t slot_bytes = 0;
+    } dist;
+    std::mutex dist_mu;   // collectives of one communicator are issued one at a time
     // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are
     // serialised by `mu`; WAITING for the GPU happens outside it, so calls issued from different threads -- e.g. the libuv
     // workers behind two unresolved JS promises -- overlap on the GPU like explicitly pipelined ones.  A synchronous call that

@@ -47,6 +47,10 @@ static int (*p_conv[6])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
 static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
+static int (*p_dist_id)(uint8_t *);
+static int (*p_dist_init)(msm_amd_ctx *, int, int, const uint8_t *);
+static int (*p_dist_destroy)(msm_amd_ctx *);
+static int (*p_multiexp_dist)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint8_t *);
 
 static const char *load_engine(void) {
     if (g_lib) return NULL;
@@ -95,6 +99,10 @@ static const char *load_engine(void) {
     SYM(p_glv_dec, "msm_amd_glv_decompose_scalar")
     SYM(p_glv_endo, "msm_amd_glv_endomorphism")
     SYM(p_glv_pre, "msm_amd_glv_preprocess")
+    SYM(p_dist_id, "msm_amd_dist_unique_id")
+    SYM(p_dist_init, "msm_amd_dist_init")
+    SYM(p_dist_destroy, "msm_amd_dist_destroy")
+    SYM(p_multiexp_dist, "msm_amd_multiexp_dist")
 #undef SYM
     return NULL;
 }
@@ -203,7 +211,7 @@ static int parse_call(napi_env env, napi_callback_info info, call_t *c, int is_c
     size_t argc = 10;
     napi_value argv[10];
     if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return -1;
-    size_t need = is_chunk ? 10 : 8;
+    size_t need = is_chunk == 1 ? 10 : 8;   /* is_chunk: 0 = multiexp, 1 = _chunk, 2 = the multi-GPU form (msm_amd_multiexp_dist) */
     void *ctx;
     size_t lb, ls;
     if (argc < need || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &c->curve) ||
@@ -214,7 +222,7 @@ static int parse_call(napi_env env, napi_callback_info info, call_t *c, int is_c
     }
     c->ctx = (msm_amd_ctx *)ctx;
     c->is_chunk = is_chunk;
-    if (is_chunk && (get_u32(env, argv[8], &c->start_bit) || get_u32(env, argv[9], &c->chunk_size))) {
+    if (is_chunk == 1 && (get_u32(env, argv[8], &c->start_bit) || get_u32(env, argv[9], &c->chunk_size))) {
         napi_throw_type_error(env, NULL, "startBit and chunkSize must be unsigned integers");
         return -1;
     }
@@ -235,7 +243,9 @@ static int parse_call(napi_env env, napi_callback_info info, call_t *c, int is_c
     return 0;
 }
 static void run_call(call_t *c) {
-    if (c->is_chunk)
+    if (c->is_chunk == 2)
+        c->rc = p_multiexp_dist(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->out);
+    else if (c->is_chunk)
         c->rc = p_multiexp_chunk(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->start_bit, c->chunk_size, c->out);
     else
         c->rc = p_multiexp(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->out);
@@ -308,6 +318,62 @@ static napi_value js_multiexp_async_common(napi_env env, napi_callback_info info
     return promise;
 }
 static napi_value js_multiexp_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 0); }
+/* multi-GPU (one Node process per GPU): this rank's windows + one RCCL all-gather of the partials, behind msm_amd_multiexp_dist */
+static napi_value js_multiexp_dist(napi_env env, napi_callback_info info) { return js_multiexp_common(env, info, 2); }
+static napi_value js_multiexp_dist_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 2); }
+/* distUniqueId() -> Uint8Array(128): rank 0 creates it and hands it to the other processes (IPC, a file, an env var ...) */
+static napi_value js_dist_unique_id(napi_env env, napi_callback_info info) {
+    (void)info;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    uint8_t id[128];
+    if (p_dist_id(id)) {
+        napi_throw_error(env, "MSM_AMD_EHIP", "msm_amd_dist_unique_id failed (RCCL not loadable?)");
+        return NULL;
+    }
+    napi_value ab, arr;
+    void *data;
+    NAPI_OK(napi_create_arraybuffer(env, sizeof id, &data, &ab));
+    memcpy(data, id, sizeof id);
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, sizeof id, ab, 0, &arr));
+    return arr;
+}
+/* distInit(ctx, rank, world, id) -- collective over the `world` processes; distDestroy(ctx) */
+static napi_value js_dist_init(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int rank, world;
+    const uint8_t *id;
+    size_t len;
+    if (argc < 4 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &rank) || get_i32(env, argv[2], &world) ||
+        get_bytes(env, argv[3], &id, &len) || len < 128) {
+        napi_throw_type_error(env, NULL, "distInit(ctx, rank, world, id:Uint8Array(128))");
+        return NULL;
+    }
+    if (p_dist_init((msm_amd_ctx *)ctx, rank, world, id)) {
+        char msg[320];
+        snprintf(msg, sizeof msg, "msm_amd_dist_init: %s", p_last_error((msm_amd_ctx *)ctx));
+        napi_throw_error(env, "MSM_AMD_ERROR", msg);
+    }
+    return NULL;
+}
+static napi_value js_dist_destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    if (argc < 1 || napi_get_value_external(env, argv[0], &ctx) != napi_ok) {
+        napi_throw_type_error(env, NULL, "distDestroy(ctx)");
+        return NULL;
+    }
+    p_dist_destroy((msm_amd_ctx *)ctx);
+    return NULL;
+}
 static napi_value js_multiexp_chunk_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 1); }
 
 /* ---- host-only helpers: normalize / toAffine / eq / combine / Montgomery conversion -------- */
@@ -695,6 +761,11 @@ static napi_value init(napi_env env, napi_value exports) {
         {"multiexpChunk", NULL, js_multiexp_chunk, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpAsync", NULL, js_multiexp_async, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpChunkAsync", NULL, js_multiexp_chunk_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpDist", NULL, js_multiexp_dist, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpDistAsync", NULL, js_multiexp_dist_async, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"distUniqueId", NULL, js_dist_unique_id, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"distInit", NULL, js_dist_init, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"distDestroy", NULL, js_dist_destroy, NULL, NULL, NULL, napi_enumerable, NULL},
         {"normalize", NULL, js_normalize, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toAffine", NULL, js_to_affine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"eq", NULL, js_eq, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -122,15 +122,35 @@ function instantiate(curveName, imports, opts) {
 function curve(curveName, opts) {
     const C = lookup(curveName);
     const ctx = context(opts && opts.device);
+    const maxSlice = (opts && opts.maxSlice) || (1 << 22);
+    const dist = opts && opts.dist;
+    if (dist) native.distInit(ctx, dist.rank, dist.world, dist.id);
     const group = (g) => {
         const fsz = C.n8 * g;
+        // ffjavascript's G.multiExp[Affine] (package ffjavascript@0.2.56, NOT in the reference tree: behaviour modelled from upstream
+        // knowledge, parity unpinned at this level -- SURVEY.md 8b): n = bases / point size, scalarSize = scalars / n, the points are cut
+        // into slices of at most 2^22, every slice is one multi-exponentiation (there: one `_chunk` task per window on a worker pool,
+        // Horner on the main thread; here: one engine call, windows and Horner inside it) and the slice results are added.
+        // opts.dist = {rank, world, id}: this process is one rank of a multi-GPU group (msm_amd_dist_*; every rank makes the same calls).
+        const call = dist ? native.multiexpDistAsync : native.multiexpAsync;
         const run = (flags, stride) => async function (buffBases, buffScalars) {
             const n = Math.floor(buffBases.byteLength / stride);
             if (n * stride !== buffBases.byteLength) throw new RangeError("bases length is not a whole number of points");
             if (n === 0) return native.combine(C.id, g, new Uint8Array(0));
             const scalarSize = Math.floor(buffScalars.byteLength / n);
             if (scalarSize * n !== buffScalars.byteLength) throw new RangeError("scalars length is not a multiple of the number of points");
-            return native.multiexpAsync(ctx, C.id, g, flags, buffBases, buffScalars, scalarSize, n);
+            if (n <= maxSlice) return call(ctx, C.id, g, flags, buffBases, buffScalars, scalarSize, n);
+            const parts = [];
+            for (let i = 0; i < n; i += maxSlice) {
+                const m = Math.min(maxSlice, n - i);
+                parts.push(call(ctx, C.id, g, flags, buffBases.subarray(i * stride, (i + m) * stride),
+                                buffScalars.subarray(i * scalarSize, (i + m) * scalarSize), scalarSize, m));
+                if (parts.length >= 2) await parts[parts.length - 2];      // at most two slices in flight (the engine's two slots)
+            }
+            const res = await Promise.all(parts);
+            const jsz = 3 * fsz, all = new Uint8Array(res.length * jsz);
+            res.forEach((r, k) => all.set(r, k * jsz));
+            return native.combine(C.id, g, all);
         };
         return {
             F: { n8: fsz },
@@ -170,4 +190,7 @@ function curve(curveName, opts) {
     return { name: curveName, n8q: C.n8, n8r: 32, Fr, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c) };
 }
 
-module.exports = { instantiate, curve, native, CURVES };
+/** 128-byte id of a multi-GPU group: rank 0 creates it and hands it to the other processes (msm_amd_dist_unique_id) */
+const distUniqueId = () => native.distUniqueId();
+
+module.exports = { instantiate, curve, native, CURVES, distUniqueId, FLAG_JACOBIAN, FLAG_BASES_IN_SUBGROUP: 16 };

@@ -158,6 +158,21 @@ async function main() {
         outs.forEach((o, k) => { if (Buffer.from(o).toString("hex") !== canon(jobs[k].out_norm, 48, zeroHex)) throw new Error("concurrent promises: result differs"); });
         checked += outs.length;
     }
+    // the ffjavascript-shaped surface cuts inputs beyond maxSlice points into slices and adds the slice results (2^22 there; lowered
+    // here so that the path runs at golden sizes), and the multi-GPU form of the same surface with a group of one rank
+    if (!hostOnly) {
+        const G = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_bls12381.json"))).groups.g1;
+        const pool = fs.readFileSync(path.join(GOLD, G.pool_file));
+        const r = G.msm.find((x) => x.id === "rand_n4096" && x.fn === "multiexpAffine");
+        const [b, sc] = inputs("bls12381", G, pool, r, 96);
+        const zeroHex = Buffer.from(msm.native.combine(0, 1, new Uint8Array(0))).toString("hex");
+        const sliced = await msm.curve("bls12381", { device: 0, maxSlice: 1000 }).G1.multiExpAffine(b, sc);
+        if (Buffer.from(sliced).toString("hex") !== canon(r.out_norm, 48, zeroHex)) throw new Error("sliced multiExpAffine differs");
+        const one = msm.curve("bls12381", { device: 0, maxSlice: 1500, dist: { rank: 0, world: 1, id: msm.distUniqueId() } });
+        const viaDist = await one.G1.multiExpAffine(b, sc);
+        if (Buffer.from(viaDist).toString("hex") !== canon(r.out_norm, 48, zeroHex)) throw new Error("multi-GPU form (world of one) differs");
+        checked += 2;
+    }
     // FFTs (tests/golden/golden_fft.json), in place through the export-shaped surface
     if (!hostOnly) {
         const ff = JSON.parse(fs.readFileSync(path.join(GOLD, "golden_fft.json")));

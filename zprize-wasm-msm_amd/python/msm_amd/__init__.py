@@ -73,6 +73,13 @@ def load_library(path=None):
     L.msm_amd_multiexp_chunk.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_multiexp_shard.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u32, u8p]
     L.msm_amd_combine.argtypes = [c.c_int, c.c_int, vp, u32, u8p]
+    L.msm_amd_dist_unique_id.argtypes = [u8p]
+    L.msm_amd_dist_init.argtypes = [vp, c.c_int, c.c_int, vp]
+    L.msm_amd_dist_destroy.argtypes = [vp]
+    L.msm_amd_dist_info.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    L.msm_amd_multiexp_dist.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
+    L.msm_amd_multiexp_dist_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, c.POINTER(c.c_uint64)]
+    L.msm_amd_dist_wait.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u8p]
     L.msm_amd_normalize.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_to_affine.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
@@ -184,6 +191,14 @@ class Engine:
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
 
+    # --- multi-GPU group (RCCL behind the C ABI: msm_amd_dist_*) -------------------------------------------
+    def dist_init(self, rank, world, unique_id):
+        """Join the group of `world` contexts (one per GPU / process); `unique_id` = the 128 bytes rank 0 got from dist_unique_id()."""
+        self._chk(self.L.msm_amd_dist_init(self.ctx, int(rank), int(world), bytes(unique_id)))
+
+    def dist_destroy(self):
+        self._chk(self.L.msm_amd_dist_destroy(self.ctx))
+
     def timings(self):
         arr = (ctypes.c_float * 8)()
         k = self.L.msm_amd_get_timings(self.ctx, arr, 8)
@@ -206,6 +221,16 @@ class Ticket:
     def wait(self):
         out = ctypes.create_string_buffer(self.curve.jacobian_bytes(self.group))
         self.curve.eng._chk(self.curve.eng.L.msm_amd_wait(self.curve.eng.ctx, self.value, out))
+        self._keep = None
+        return out.raw
+
+
+class DistTicket(Ticket):
+    """Handle of a queued sharded MSM of a multi-GPU group; wait() exchanges the partials over RCCL and returns the sum."""
+
+    def wait(self):
+        out = ctypes.create_string_buffer(self.curve.jacobian_bytes(self.group))
+        self.curve.eng._chk(self.curve.eng.L.msm_amd_dist_wait(self.curve.eng.ctx, self.curve.cid, self.group, self.value, out))
         self._keep = None
         return out.raw
 
@@ -305,6 +330,24 @@ class Curve:
                                                               shard, nshards, ctypes.byref(t)))
         return Ticket(self, group, t.value, (kb, ks))
 
+    def multiexp_dist(self, group, bases, scalars, scalar_size, n, jacobian_bases=False):
+        """msm_amd_multiexp_dist: this rank's windows on this rank's GPU, one ncclAllGather of the partials, the sum (same bytes on
+        every rank).  The engine must have joined a group (Engine.dist_init)."""
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | self._residency_flags(dev_b, dev_s)
+        out = ctypes.create_string_buffer(self.jacobian_bytes(group))
+        self.eng._chk(self.eng.L.msm_amd_multiexp_dist(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, out))
+        return out.raw
+
+    def multiexp_dist_async(self, group, bases, scalars, scalar_size, n, jacobian_bases=False):
+        pb, dev_b, kb = _as_ptr(bases)
+        ps, dev_s, ks = _as_ptr(scalars)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | self._residency_flags(dev_b, dev_s)
+        t = ctypes.c_uint64()
+        self.eng._chk(self.eng.L.msm_amd_multiexp_dist_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, ctypes.byref(t)))
+        return DistTicket(self, group, t.value, (kb, ks))
+
     # --- batch conversions either side of the MSM (the reference's g?m_batch* exports), host buffers ---------
     def _conv(self, fn, group, data, in_sz, out_sz):
         data = bytes(data)
@@ -398,6 +441,15 @@ class Curve:
         buf = self.eng.alloc(max(16, n * self.affine_bytes(group)))
         self.eng._chk(self.eng.L.msm_amd_gen_points(self.eng.ctx, self.cid, group, seed, n, buf.ptr))
         return buf
+
+
+def dist_unique_id():
+    """128-byte RCCL id (msm_amd_dist_unique_id); rank 0 creates it and hands it to the other ranks."""
+    L = load_library()
+    out = ctypes.create_string_buffer(128)
+    if L.msm_amd_dist_unique_id(out):
+        raise MsmAmdError("msm_amd_dist_unique_id failed (RCCL not loadable?)")
+    return out.raw
 
 
 # --- host-only helpers (no GPU, no context): the comparison functions the reference's tests use ---
