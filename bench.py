@@ -181,7 +181,26 @@ def main():
         h_pts = np.frombuffer(pts.download(n * C.affine_bytes(g)), dtype=np.uint8).copy()
         h_sc = np.ascontiguousarray(sc_host)
 
+    # N > 1: the exchange of the window partials runs behind the C ABI (msm_amd_dist_*: the engine's own RCCL communicator, ONE
+    # ncclAllGather per call) -- the path a Node host takes.  torch.distributed only carries the 128-byte id, the barrier and the MAX
+    # over ranks.  The gloo rehearsal (ranks sharing one GPU, which RCCL refuses) and a failed msm_amd_dist_init fall back to the
+    # torch.distributed form of the same exchange (msm_amd.dist), and the JSON line says which one ran.
+    exchange = None
+    if sharded:
+        exchange = "torch.distributed all_gather_into_tensor (msm_amd.dist)"
+        if backend == "nccl":
+            try:
+                box = [msm_amd.dist_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                eng.dist_init(rank, world, box[0])
+                exchange = "C ABI: msm_amd_multiexp_dist_async / msm_amd_dist_wait (ncclAllGather on the engine's own communicator)"
+            except msm_amd.MsmAmdError as e:
+                print(f"bench.py: msm_amd_dist_init failed on rank {rank} ({e}); exchanging through torch.distributed", file=sys.stderr)
+    cabi = bool(exchange and exchange.startswith("C ABI"))
+
     def step():
+        if cabi:
+            return C.multiexp_dist(g, pts, d_scalars, 32, n)
         if args.host_buffers:
             return C._multiexp(g, 0, pts if args.resident_bases else h_pts, h_sc, 32, n)
         if not sharded:
@@ -218,8 +237,8 @@ def main():
     gathering = []   # all_gathers started and not yet collected (at most one is left running behind the loop)
 
     def finish(ticket):
-        out = ticket.wait()
-        if not sharded:
+        out = ticket.wait()      # C ABI form: waits for this rank's partial, all-gathers, adds -- the combined result
+        if not sharded or cabi:
             return out
         # this rank's partial is ready: ONE all_gather of world x 144 B over RCCL/xGMI, started asynchronously; the
         # previous call's gathered partials are collected and added on the host meanwhile
@@ -235,7 +254,7 @@ def main():
             if not sharded:
                 inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
             else:
-                inflight.append(C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
+                inflight.append(C.multiexp_dist_async(g, pts, d_scalars, 32, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
             if len(inflight) == depth:
                 result = finish(inflight.pop(0))
                 collect()
@@ -317,7 +336,8 @@ def main():
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
-                       "parallelism": "1 GPU" if not sharded else f"windows sharded over {world} GPUs + RCCL all_gather of partials"},
+                       "parallelism": "1 GPU" if not sharded else f"windows sharded over {world} GPUs + RCCL all_gather of partials",
+                       "exchange": exchange},
             "mode": (f"pipelined({depth}): {depth} calls in flight, every call collected inside the timed region" if pipelined else "one call at a time"),
             # the dominant kernel is integer-ALU bound: its roofline is the VALU issue rate of v_mad_u64_u32 (MADS_PER_ADD of them per
             # bucket addition, field_u.hpp / curve_u.hpp).  Peak: measured on this chip with tools/microbench/valu_rates.hip

@@ -213,6 +213,27 @@ int msm_amd_fr_batch_apply_key(msm_amd_ctx *ctx, int curve, uint32_t flags, cons
  * MSM_AMD_DEVICE_PTRS.  The reference transforms in place; here in -> out (they may be the same buffer).           */
 int msm_amd_fft(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *in, uint32_t n, void *out);
 
+/* Building blocks of the blocked FFT (what ffjavascript drives for transforms larger than one WASM instance), build_fft.js:657-1353,
+ * for group = 0 (Fr elements: 32 bytes Montgomery, byte-identical to frm_*) and 1 / 2 (Jacobian points in, NORMALISED Jacobian points
+ * out, as g1m_* / g2m_*).  All transform their buffers IN PLACE, as the reference does.  first32 / inc32 / factor32: Fr elements in
+ * Montgomery form; the reference's running key t = t * inc becomes first * inc^i computed by lane i.
+ *   msm_amd_fft_join                    <p>_fftJoin(pBuff1, pBuff2, n, first, inc)                     :657-746
+ *   msm_amd_fft_join_ext                <p>_fftJoinExt(..., totalBits); with MSM_AMD_FFT_INVERSE: <p>_fftJoinExtInv   :749-988
+ *   msm_amd_prepare_lagrange_evaluation <p>_prepareLagrangeEvaluation(pBuff1, pBuff2, n, first, inc, totalBits)    :991-1112
+ *   msm_amd_fft_mix                     <p>_fftMix(pBuff, n, exp): one radix-2 pass of span 2^exp      :1114-1236
+ *   msm_amd_fft_final                   <p>_fftFinal(pBuff, n, factor): out[i] = factor * in[n-1-i]    :1238-1353
+ *   msm_amd_fr_batch_montgomery         frm_batchToMontgomery / frm_batchFromMontgomery (build_batchconvertion.js), to_montgomery = 1 / 0 */
+int msm_amd_fft_join(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, void *buff1, void *buff2, uint32_t n,
+                     const uint8_t *first32, const uint8_t *inc32);
+int msm_amd_fft_join_ext(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, void *buff1, void *buff2, uint32_t n,
+                         const uint8_t *first32, const uint8_t *inc32, uint32_t total_bits);
+int msm_amd_prepare_lagrange_evaluation(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, void *buff1, void *buff2,
+                                        uint32_t n, const uint8_t *first32, const uint8_t *inc32, uint32_t total_bits);
+int msm_amd_fft_mix(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, void *buff, uint32_t n, uint32_t exp);
+int msm_amd_fft_final(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, void *buff, uint32_t n, const uint8_t *factor32);
+int msm_amd_fr_batch_montgomery(msm_amd_ctx *ctx, int curve, uint32_t flags, const void *in, uint32_t n, int to_montgomery,
+                                void *out);
+
 /* ---- GLV pre-pass for BLS12-381 G1 (reference: wasmcurves/src/build_glv.js) ------- */
 /* g1m_glv_decomposeScalar (:53-146): 32-byte scalar k -> out64 = |k1| (16 bytes, then 16 zero) || |k2| (same),
  * *sign bit 0 = (k1 >= 0), bit 1 = (k2 >= 0), with k = k1 + k2*lambda (mod r).  Host only.               */

@@ -183,6 +183,64 @@ def test_all_equal_scalars_take_the_long_span_paths(eng, orc):
         eng.set_option("sort_big", 0)
 
 
+def test_blocked_fft_building_blocks_match_the_reference(eng, orc):
+    """<p>_fftJoin / _fftJoinExt / _fftJoinExtInv / _prepareLagrangeEvaluation / _fftMix / _fftFinal for p = frm (byte for byte), g1m, g2m
+    (as normalised points) and frm_batchTo/FromMontgomery == the reference WASM (tests/golden/golden_fft2.json, oracle/gen_golden_fft2.js).
+    Size-independent check on top: a 2^12-point Fr transform assembled from its fftMix passes equals frm_fft of the bit-reversed input."""
+    with open(os.path.join(gu.GOLDEN, "golden_fft2.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        C = eng.curve(c["curve"])
+        g = c["group"]
+        if g == -1:
+            plain, mont = bytes.fromhex(c["plain"]), bytes.fromhex(c["mont"])
+            assert C.frm_batchToMontgomery(plain) == mont
+            assert C.frm_batchFromMontgomery(mont) == bytes.fromhex(c["back"]) == plain
+            continue
+        in1, in2 = bytes.fromhex(c["in1"]), bytes.fromhex(c["in2"])
+        first, inc, factor = (bytes.fromhex(c[k]) for k in ("first", "inc", "factor"))
+        if g:
+            O = orc.Oracle(c["curve"], g)
+            zero, jsz = O.zero(), O.jsz
+
+            def canon(hx):
+                b = bytes.fromhex(hx)
+                return b"".join(gu.canon(c["curve"], g, b[i:i + jsz], zero) for i in range(0, len(b), jsz))
+        else:
+            def canon(hx):
+                return bytes.fromhex(hx)
+        for name, exp in c["ops"].items():
+            op, _, arg = name.partition(":")
+            tag = (c["curve"], g, c["n"], name)
+            if op == "fftJoin":
+                got = C.fft_join(g, in1, in2, first, inc)
+            elif op == "fftJoinExt":
+                got = C.fft_join_ext(g, in1, in2, first, inc, int(arg))
+            elif op == "fftJoinExtInv":
+                got = C.fft_join_ext(g, in1, in2, first, inc, int(arg), inverse=True)
+            elif op == "prepareLagrangeEvaluation":
+                got = C.prepare_lagrange_evaluation(g, in1, in2, first, inc, int(arg))
+            elif op == "fftMix":
+                got = (C.fft_mix(g, in1, int(arg)),)
+            elif arg == "odd3":
+                got = (C.fft_final(g, in1[:3 * 32], factor),)
+            else:
+                got = (C.fft_final(g, in1, factor),)
+            assert got[0] == canon(exp["out1"]), tag
+            if "out2" in exp:
+                assert got[1] == canon(exp["out2"]), tag
+    # fftMix passes 1..bits over the bit-reversed input ARE the radix-2 transform
+    for curve in ("bls12381", "bn128"):
+        C = eng.curve(curve)
+        bits, r = 12, gu.R_ORDER[curve]
+        raw = gu.stream(f"gpu:fftmix:{curve}", 40 << bits)
+        x = [(int.from_bytes(raw[40 * i:40 * i + 40], "little") % r).to_bytes(32, "little") for i in range(1 << bits)]
+        buf = b"".join(x[int(format(i, f"0{bits}b")[::-1], 2)] for i in range(1 << bits))
+        for e in range(1, bits + 1):
+            buf = C.fft_mix(0, buf, e)
+        assert buf == C.frm_fft(b"".join(x))
+
+
 def test_reduce_l_must_be_a_power_of_two(eng):
     """The LDS trees of the bucket reduction halve the lane count: a lane count that is not a power of two would drop a partial
     sum (reduce_l = 200 at c = 16 gave 164 lanes).  The option refuses such values instead."""

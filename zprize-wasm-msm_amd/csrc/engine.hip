@@ -230,7 +230,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     uint32_t* sorted = (uint32_t*)sl->d_sorted.p;
 
     const uint32_t nblk = (a.n + 255) / 256;
-    const uint32_t oblk = std::max(1u, std::min(256u, NB / 8192u));
+    const uint32_t oblk = std::max(1u, std::min(512u, NB / 2048u));
     // A lone call (nothing else in flight) is latency-bound at its end: the bucket reduction is ~40 dependent additions deep
     // on one wave per SIMD.  Optionally (option "split") its windows are handled as two groups, the reduction of the first
     // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
@@ -241,7 +241,6 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     const bool split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
     const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
     const uint32_t split = w_split * g.half;                                               // first bucket of the second group
-    HIPCHK(ctx, hipMemsetAsync(bins, 0, ORDER_KEYS * 4, st));
     {
         // ---- 1. populations of the (owned window, coarse bin) pairs -- digits recomputed from the scalars, never stored
         SortGeom sg;
@@ -290,7 +289,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             msm_set_err(ctx, "too many windows x coarse bins for the histogram kernel (use a wider window)");
             return MSM_AMD_EINVAL;
         }
-        HIPCHK(ctx, hipMemsetAsync(binhist, 0, (size_t)sg.nbins * 4, st));
+        // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
+        if (sl->binhist_zero != sl->d_binhist.p) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
+        sl->binhist_zero = nullptr;   // until this submission has got as far as k_bin_scan
 #define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist)
         if (wide) {
             if (nw == 8) MSM_TILE_HIST(8, 1024);
@@ -304,7 +305,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 #undef MSM_TILE_HIST
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. bin starts
-        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur);
+        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur, bins, (uint32_t)ORDER_KEYS);
+        sl->binhist_zero = sl->d_binhist.p;
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
         // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
@@ -629,6 +631,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return MSM_AMD_EINVAL;
     }
     if (rc) {
+        sl->binhist_zero = nullptr;   // whatever the sort had counted so far is not to be trusted
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream_s);
         if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);

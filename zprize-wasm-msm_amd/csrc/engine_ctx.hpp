@@ -36,6 +36,7 @@ struct Slot {
     DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
+    const void* binhist_zero = nullptr;   // == d_binhist.p while that buffer is known to be all zero (sort: k_bin_scan leaves it so)
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts

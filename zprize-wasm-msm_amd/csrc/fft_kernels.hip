@@ -294,6 +294,130 @@ __global__ void __launch_bounds__(256) k_g_fft_final(const uint8_t* __restrict__
     store16(out + (size_t)i * sizeof(Jacobian<F>), o);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Building blocks of the blocked FFT (what ffjavascript drives for transforms larger than one WASM instance):
+//   <p>_fftJoin / _fftJoinExt / _fftJoinExtInv / _prepareLagrangeEvaluation (build_fft.js:657-1112)  element-wise over two buffers,
+//        with the running key W_i = first * inc^i (the reference walks i sequentially; lane i raises inc to the i-th power itself);
+//   <p>_fftMix (:1114-1236) one radix-2 pass of span 2^exp;   <p>_fftFinal (:1238-1353) out[i] = factor * in[n-1-i].
+// One element type per instantiation: FrEl (32-byte Montgomery scalars, byte-identical to the reference) or PtEl<F> (Jacobian points
+// in, NORMALISED Jacobian points out; the scalar product is g?m_timesFr).  SM / SC = SHIFT_TO_M[totalBits] / SCONST[totalBits].
+// ------------------------------------------------------------------------------------------
+template <class P>
+struct FrEl {
+    using Params = P;
+    static constexpr size_t BYTES = 32;
+    uint32_t v[8];
+    MSM_D static FrEl load(const uint8_t* p) {
+        FrEl e;
+        const uint4* s = reinterpret_cast<const uint4*>(p);
+        uint4 a = s[0], b = s[1];
+        e.v[0] = a.x; e.v[1] = a.y; e.v[2] = a.z; e.v[3] = a.w; e.v[4] = b.x; e.v[5] = b.y; e.v[6] = b.z; e.v[7] = b.w;
+        return e;
+    }
+    MSM_D void store(uint8_t* p) const {
+        uint4* d = reinterpret_cast<uint4*>(p);
+        d[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        d[1] = make_uint4(v[4], v[5], v[6], v[7]);
+    }
+    MSM_D static FrEl add(const FrEl& a, const FrEl& b) { FrEl r; fr_add<P>(a.v, b.v, r.v); return r; }
+    MSM_D static FrEl sub(const FrEl& a, const FrEl& b) { FrEl r; fr_sub<P>(a.v, b.v, r.v); return r; }
+    MSM_D static FrEl times(const FrEl& a, const uint32_t* w_mont) { FrEl r; fr_mul<P>(a.v, w_mont, r.v); return r; }
+};
+template <class F>
+struct PtEl {
+    using Params = typename F::Params;
+    static constexpr size_t BYTES = sizeof(Jacobian<F>);
+    XYZZ<F> p;
+    MSM_D static PtEl load(const uint8_t* q) { return {XYZZ<F>::from_jacobian(load16<Jacobian<F>>(q))}; }
+    MSM_D void store(uint8_t* q) const {
+        Jacobian<F> o;
+        if (p.is_inf()) {
+            o = {F::zero(), F::one(), F::zero()};
+        } else {
+            Affine<F> a = Affine<F>::canon(XYZZ<F>::to_affine(p));
+            o = {a.x, a.y, F::one()};
+        }
+        store16(q, o);
+    }
+    MSM_D static PtEl add(const PtEl& a, const PtEl& b) { PtEl r; XYZZ<F>::add_to(r.p, a.p, b.p); return r; }
+    MSM_D static PtEl sub(const PtEl& a, const PtEl& b) { PtEl r; const XYZZ<F> nb = XYZZ<F>::neg(b.p); XYZZ<F>::add_to(r.p, a.p, nb); return r; }
+    MSM_D static PtEl times(const PtEl& a, const uint32_t* w_mont) { return {g_times_fr<F>(a.p, w_mont)}; }
+};
+enum { FFT_OP_JOIN = 0, FFT_OP_JOIN_EXT = 1, FFT_OP_JOIN_EXT_INV = 2, FFT_OP_PREP_LAGRANGE = 3 };
+// key = first || inc || SM || SC (4 x 8 words, Montgomery)
+template <class E, int OP>
+__global__ void __launch_bounds__(256) k_fft_pair_op(uint8_t* __restrict__ b1, uint8_t* __restrict__ b2, uint32_t n, const uint32_t* __restrict__ key) {
+    using P = typename E::Params;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t w[8], sm[8], sc[8];
+    fr_key<P>(key, key + 8, i, w);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sm[k] = key[16 + k];
+        sc[k] = key[24 + k];
+    }
+    E a = E::load(b1 + (size_t)i * E::BYTES), b = E::load(b2 + (size_t)i * E::BYTES);
+    if constexpr (OP == FFT_OP_JOIN) {                    // T = W b; (a, b) <- (a + T, a - T)                       :657-746
+        const E t = E::times(b, w);
+        const E u = a;
+        a = E::add(u, t);
+        b = E::sub(u, t);
+    } else if constexpr (OP == FFT_OP_JOIN_EXT) {          // U = a + b; b <- W (a + SM b); a <- U                     :749-857
+        const E u = E::add(a, b);
+        b = E::times(E::add(a, E::times(b, sm)), w);
+        a = u;
+    } else if constexpr (OP == FFT_OP_JOIN_EXT_INV) {      // U = W b; b <- SC (a - U); a <- SC (U - SM a)             :860-988
+        const E u = E::times(b, w);
+        b = E::times(E::sub(a, u), sc);
+        a = E::times(E::sub(u, E::times(a, sm)), sc);
+    } else {                                               // U = b - SM a; b <- W (a - b); a <- SC U                  :991-1112
+        const E u = E::sub(b, E::times(a, sm));
+        b = E::times(E::sub(a, b), w);
+        a = E::times(u, sc);
+    }
+    a.store(b1 + (size_t)i * E::BYTES);
+    b.store(b2 + (size_t)i * E::BYTES);
+}
+// one radix-2 pass of span 2^exp over the whole buffer (every group of 2^exp elements; twiddle omega_(2^exp)^j from the table)
+template <class E>
+__global__ void __launch_bounds__(256) k_fft_mix(uint8_t* __restrict__ buf, uint32_t n, uint32_t exp, const uint32_t* __restrict__ tw) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t h = 1u << (exp - 1), groups = n >> exp;
+    if (idx >= groups * h) return;
+    const uint32_t j = idx & (h - 1), i1 = ((idx >> (exp - 1)) << exp) + j, i2 = i1 + h;
+    uint32_t w[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[k] = tw[(size_t)j * 8 + k];
+    const E u = E::load(buf + (size_t)i1 * E::BYTES);
+    const E t = E::times(E::load(buf + (size_t)i2 * E::BYTES), w);
+    E::add(u, t).store(buf + (size_t)i1 * E::BYTES);
+    E::sub(u, t).store(buf + (size_t)i2 * E::BYTES);
+}
+// out[i] = factor * in[n - 1 - i]  (in != out)
+template <class E>
+__global__ void __launch_bounds__(256) k_fft_final(const uint8_t* __restrict__ in, uint32_t n, const uint32_t* __restrict__ factor, uint8_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = factor[k];
+    E::times(E::load(in + (size_t)(n - 1 - i) * E::BYTES), f).store(out + (size_t)i * E::BYTES);
+}
+// frm_batchToMontgomery / frm_batchFromMontgomery (build_batchconvertion.js over frm_toMontgomery = mul by R^2, frm_fromMontgomery = mul by 1)
+template <class P>
+__global__ void __launch_bounds__(256) k_fr_batch_mont(const uint8_t* __restrict__ in, uint32_t n, uint32_t to, uint8_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t m[8] = {1u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    if (to) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = P::FR_R2[k];
+    }
+    FrEl<P>::times(FrEl<P>::load(in + (size_t)i * 32), m).store(out + (size_t)i * 32);
+}
+
 }  // namespace msm
 
 // ---- batchApplyKey ----------------------------------------------------------------------------
@@ -425,6 +549,110 @@ static int g_fft_t(msm_amd_ctx* ctx, uint32_t flags, const void* in, uint32_t n,
     return 0;
 }
 
+// ---- blocked-FFT helpers ------------------------------------------------------------------------
+// which: 0..3 = pair operations (FFT_OP_*), 4 = fftMix (arg = exp), 5 = fftFinal (key32 = factor).  Buffers are transformed in place.
+template <class E>
+static int fft_helper_t(msm_amd_ctx* ctx, int which, uint32_t flags, void* b1, void* b2, uint32_t n, const uint8_t* first32, const uint8_t* inc32,
+                        uint32_t arg) {
+    using P = typename E::Params;
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const size_t bytes = (size_t)n * E::BYTES;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (dev && (((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15))) {
+        msm_set_err(ctx, "device pointers must be 16-byte aligned");
+        return MSM_AMD_EINVAL;
+    }
+    const bool pair = which <= 3;
+    if ((pair || which == 4) && arg > (uint32_t)P::FR_MAXBITS) {
+        msm_set_err(ctx, "totalBits / exp beyond the 2-adicity of the scalar field");
+        return MSM_AMD_EINVAL;
+    }
+    if (which == 4 && (arg == 0 || (n & ((1u << arg) - 1)) != 0)) {
+        msm_set_err(ctx, "fftMix: n must be a multiple of 2^exp, exp >= 1");
+        return MSM_AMD_EINVAL;
+    }
+    void *d1 = b1, *d2 = b2, *dkey = nullptr, *dtw = nullptr, *dtmp = nullptr;
+    hipError_t e = hipMalloc(&dkey, 128);
+    if (e == hipSuccess && !dev) {
+        e = hipMalloc(&d1, bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(d1, b1, bytes, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && pair) {
+            e = hipMalloc(&d2, bytes);
+            if (e == hipSuccess) e = hipMemcpyAsync(d2, b2, bytes, hipMemcpyHostToDevice, st);
+        }
+    }
+    uint8_t key[128];
+    memset(key, 0, sizeof key);
+    if (first32) memcpy(key, first32, 32);
+    if (inc32) memcpy(key + 32, inc32, 32);
+    if (pair) {
+        memcpy(key + 64, P::FR_SHIFT_TO_M[arg], 32);
+        memcpy(key + 96, P::FR_SCONST[arg], 32);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(dkey, key, 128, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        const uint32_t nb = (n + 255) / 256;
+        uint8_t *p1 = (uint8_t*)d1, *p2 = (uint8_t*)d2;
+        const uint32_t* k = (const uint32_t*)dkey;
+        if (which == FFT_OP_JOIN) k_fft_pair_op<E, FFT_OP_JOIN><<<nb, 256, 0, st>>>(p1, p2, n, k);
+        else if (which == FFT_OP_JOIN_EXT) k_fft_pair_op<E, FFT_OP_JOIN_EXT><<<nb, 256, 0, st>>>(p1, p2, n, k);
+        else if (which == FFT_OP_JOIN_EXT_INV) k_fft_pair_op<E, FFT_OP_JOIN_EXT_INV><<<nb, 256, 0, st>>>(p1, p2, n, k);
+        else if (which == FFT_OP_PREP_LAGRANGE) k_fft_pair_op<E, FFT_OP_PREP_LAGRANGE><<<nb, 256, 0, st>>>(p1, p2, n, k);
+        else if (which == 4) {
+            e = fft_twiddles<P>(st, 1u << arg, arg, &dtw);
+            if (e == hipSuccess) k_fft_mix<E><<<(n / 2 + 255) / 256, 256, 0, st>>>(p1, n, arg, (const uint32_t*)dtw);
+        } else {
+            e = hipMalloc(&dtmp, bytes);
+            if (e == hipSuccess) {
+                k_fft_final<E><<<nb, 256, 0, st>>>(p1, n, k, (uint8_t*)dtmp);
+                e = hipMemcpyAsync(d1, dtmp, bytes, hipMemcpyDeviceToDevice, st);
+            }
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    if (!dev && e == hipSuccess) {
+        e = hipMemcpyAsync(b1, d1, bytes, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && pair) e = hipMemcpyAsync(b2, d2, bytes, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    else (void)hipStreamSynchronize(st);
+    if (dkey) (void)hipFree(dkey);
+    if (dtw) (void)hipFree(dtw);
+    if (dtmp) (void)hipFree(dtmp);
+    if (!dev) {
+        if (d1 && d1 != b1) (void)hipFree(d1);
+        if (d2 && d2 != b2) (void)hipFree(d2);
+    }
+    if (e != hipSuccess) {
+        msm_set_err(ctx, std::string("fft helper: ") + hipGetErrorString(e));
+        return MSM_AMD_EHIP;
+    }
+    return 0;
+}
+static int fft_helper(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flags, void* b1, void* b2, uint32_t n, const uint8_t* first32,
+                      const uint8_t* inc32, uint32_t arg) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!b1 || (which <= 3 && (!b2 || !first32 || !inc32)) || (which == 5 && !first32)) {
+        msm_set_err(ctx, "null pointer");
+        return MSM_AMD_EINVAL;
+    }
+    if (curve == MSM_AMD_BLS12381) {
+        using P = Bls12381Fp;
+        if (group == 0) return fft_helper_t<FrEl<P>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+        if (group == 1) return fft_helper_t<PtEl<Fp<P>>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+        if (group == 2) return fft_helper_t<PtEl<Fp2<P>>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+    } else if (curve == MSM_AMD_BN128) {
+        using P = Bn254Fp;
+        if (group == 0) return fft_helper_t<FrEl<P>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+        if (group == 1) return fft_helper_t<PtEl<Fp<P>>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+        if (group == 2) return fft_helper_t<PtEl<Fp2<P>>>(ctx, which, flags, b1, b2, n, first32, inc32, arg);
+    }
+    msm_set_err(ctx, "unknown curve/group");
+    return MSM_AMD_EINVAL;
+}
+
 extern "C" {
 
 int msm_amd_fft(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* in, uint32_t n, void* out) {
@@ -509,6 +737,62 @@ int msm_amd_fr_batch_apply_key(msm_amd_ctx* ctx, int curve, uint32_t flags, cons
     }
     if (e != hipSuccess) {
         msm_set_err(ctx, std::string("fr_batch_apply_key: ") + hipGetErrorString(e));
+        return MSM_AMD_EHIP;
+    }
+    return 0;
+}
+
+
+int msm_amd_fft_join(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, void* buff1, void* buff2, uint32_t n, const uint8_t* first32,
+                     const uint8_t* inc32) {
+    return fft_helper(ctx, FFT_OP_JOIN, curve, group, flags, buff1, buff2, n, first32, inc32, 0);
+}
+int msm_amd_fft_join_ext(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, void* buff1, void* buff2, uint32_t n, const uint8_t* first32,
+                         const uint8_t* inc32, uint32_t total_bits) {
+    return fft_helper(ctx, (flags & MSM_AMD_FFT_INVERSE) ? FFT_OP_JOIN_EXT_INV : FFT_OP_JOIN_EXT, curve, group, flags, buff1, buff2, n, first32, inc32,
+                      total_bits);
+}
+int msm_amd_prepare_lagrange_evaluation(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, void* buff1, void* buff2, uint32_t n,
+                                        const uint8_t* first32, const uint8_t* inc32, uint32_t total_bits) {
+    return fft_helper(ctx, FFT_OP_PREP_LAGRANGE, curve, group, flags, buff1, buff2, n, first32, inc32, total_bits);
+}
+int msm_amd_fft_mix(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, void* buff, uint32_t n, uint32_t exp) {
+    return fft_helper(ctx, 4, curve, group, flags, buff, nullptr, n, nullptr, nullptr, exp);
+}
+int msm_amd_fft_final(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, void* buff, uint32_t n, const uint8_t* factor32) {
+    return fft_helper(ctx, 5, curve, group, flags, buff, nullptr, n, factor32, nullptr, 0);
+}
+int msm_amd_fr_batch_montgomery(msm_amd_ctx* ctx, int curve, uint32_t flags, const void* in, uint32_t n, int to_montgomery, void* out) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!in || !out || (curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128)) {
+        msm_set_err(ctx, "bad argument");
+        return MSM_AMD_EINVAL;
+    }
+    const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
+    const size_t bytes = (size_t)n * 32;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    void *di = const_cast<void*>(in), *dout = out;
+    hipError_t e = hipSuccess;
+    if (!dev) {
+        e = hipMalloc(&di, bytes);
+        if (e == hipSuccess) e = hipMalloc(&dout, bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(di, in, bytes, hipMemcpyHostToDevice, st);
+    }
+    if (e == hipSuccess) {
+        if (curve == MSM_AMD_BLS12381) k_fr_batch_mont<Bls12381Fp><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, to_montgomery ? 1u : 0u, (uint8_t*)dout);
+        else k_fr_batch_mont<Bn254Fp><<<(n + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, to_montgomery ? 1u : 0u, (uint8_t*)dout);
+        e = hipGetLastError();
+    }
+    if (!dev && e == hipSuccess) e = hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (!dev) {
+        if (di != in) (void)hipFree(di);
+        if (dout != out) (void)hipFree(dout);
+    }
+    if (e != hipSuccess) {
+        msm_set_err(ctx, std::string("fr_batch_montgomery: ") + hipGetErrorString(e));
         return MSM_AMD_EHIP;
     }
     return 0;

@@ -94,6 +94,12 @@ def load_library(path=None):
     L.msm_amd_batch_apply_key.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp, vp, vp]
     L.msm_amd_fr_batch_apply_key.argtypes = [vp, c.c_int, u32, vp, u32, vp, vp, vp]
     L.msm_amd_fft.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_fft_join.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, vp, vp]
+    L.msm_amd_fft_join_ext.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, vp, vp, u32]
+    L.msm_amd_prepare_lagrange_evaluation.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, vp, vp, u32]
+    L.msm_amd_fft_mix.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, u32]
+    L.msm_amd_fft_final.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, vp]
+    L.msm_amd_fr_batch_montgomery.argtypes = [vp, c.c_int, u32, vp, u32, c.c_int, vp]
     L.msm_amd_glv_decompose_scalar.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_split.argtypes = [vp, u8p, c.POINTER(u32)]
     L.msm_amd_glv_endomorphism.argtypes = [vp, u32, u8p]
@@ -408,6 +414,49 @@ class Curve:
         out = ctypes.create_string_buffer(max(1, n) * esz)
         self.eng._chk(self.eng.L.msm_amd_fft(self.eng.ctx, self.cid, group, FLAG_FFT_INVERSE if inverse else 0, data, n, out))
         return out.raw[:n * esz]
+
+    # --- building blocks of the blocked FFT (build_fft.js:657-1353); group 0 = Fr elements, 1 / 2 = Jacobian points -> normalised
+    def _elem_bytes(self, group):
+        return 32 if group == 0 else self.jacobian_bytes(group)
+
+    def _pair_op(self, fn, group, buff1, buff2, first, inc, *extra, flags=0):
+        b1, b2 = ctypes.create_string_buffer(bytes(buff1), len(buff1)), ctypes.create_string_buffer(bytes(buff2), len(buff2))
+        n = len(buff1) // self._elem_bytes(group)
+        self.eng._chk(getattr(self.eng.L, fn)(self.eng.ctx, self.cid, group, flags, b1, b2, n, bytes(first), bytes(inc), *extra))
+        return b1.raw[:len(buff1)], b2.raw[:len(buff2)]
+
+    def fft_join(self, group, buff1, buff2, first, inc):
+        """<p>_fftJoin: returns the two transformed buffers"""
+        return self._pair_op("msm_amd_fft_join", group, buff1, buff2, first, inc)
+
+    def fft_join_ext(self, group, buff1, buff2, first, inc, total_bits, inverse=False):
+        """<p>_fftJoinExt / <p>_fftJoinExtInv"""
+        return self._pair_op("msm_amd_fft_join_ext", group, buff1, buff2, first, inc, int(total_bits), flags=FLAG_FFT_INVERSE if inverse else 0)
+
+    def prepare_lagrange_evaluation(self, group, buff1, buff2, first, inc, total_bits):
+        return self._pair_op("msm_amd_prepare_lagrange_evaluation", group, buff1, buff2, first, inc, int(total_bits))
+
+    def fft_mix(self, group, buff, exp):
+        """<p>_fftMix: one radix-2 pass of span 2^exp"""
+        b = ctypes.create_string_buffer(bytes(buff), len(buff))
+        self.eng._chk(self.eng.L.msm_amd_fft_mix(self.eng.ctx, self.cid, group, 0, b, len(buff) // self._elem_bytes(group), int(exp)))
+        return b.raw[:len(buff)]
+
+    def fft_final(self, group, buff, factor):
+        """<p>_fftFinal: out[i] = factor * in[n - 1 - i]"""
+        b = ctypes.create_string_buffer(bytes(buff), len(buff))
+        self.eng._chk(self.eng.L.msm_amd_fft_final(self.eng.ctx, self.cid, group, 0, b, len(buff) // self._elem_bytes(group), bytes(factor)))
+        return b.raw[:len(buff)]
+
+    def _fr_mont(self, elems, to):
+        elems = bytes(elems)
+        n = len(elems) // 32
+        out = ctypes.create_string_buffer(max(1, n) * 32)
+        self.eng._chk(self.eng.L.msm_amd_fr_batch_montgomery(self.eng.ctx, self.cid, 0, elems, n, to, out))
+        return out.raw[:n * 32]
+
+    def frm_batchToMontgomery(self, elems): return self._fr_mont(elems, 1)
+    def frm_batchFromMontgomery(self, elems): return self._fr_mont(elems, 0)
 
     def frm_fft(self, elems): return self.fft(0, elems)
     def frm_ifft(self, elems): return self.fft(0, elems, True)
