@@ -350,7 +350,7 @@ def main():
                           "frac_one_call_at_a_time": (geom["entries"] * mads / (acc_iso * 1e-3) / 1e12 / VALU_PEAK_TMADS) if acc_iso > 0 else None,
                           "mads_per_bucket_addition": mads,
                           "peak_source": "measured: tools/microbench/valu_rates.hip, profiles/r01_valu_rates_microbench.txt (v_mad_u64_u32, 2.4 GHz)",
-                          "traffic": traffic, "traffic_note": "HBM bytes per launch from rocprofv3 --pmc (FETCH_SIZE doubled as the guide prescribes for 16-B streaming loads; on this 16-B-per-lane GATHER the factor lies between 1 and 2, see DESIGN.md 5), measured on this workload only",
+                          "traffic": traffic, "traffic_note": "HBM-side bytes per launch from rocprofv3 --pmc: 1.6 x FETCH_SIZE + WRITE_SIZE -- the guide's x2 on FETCH_SIZE holds for streaming reads; for this kernel's access pattern (random 96-byte records, 16-byte loads) tools/microbench/gather_fetch.hip measures 1.58-1.64 (profiles/r02_gather_fetch_calibration.txt); measured on this workload only",
                           "avg_launch_ms": acc_ms, "avg_launch_ms_one_call_at_a_time": acc_iso,
                           "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_launch": alg_bytes,

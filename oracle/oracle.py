@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "liboracle.so")
+# ORACLE_LIB: another build of the same source (the sanitizer leg of the CPU tests loads liboracle_san.so through it)
+_LIB = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")
 
 CURVE_ID = {"bls12381": 0, "bn128": 1}
 N8 = {"bls12381": 48, "bn128": 32}
@@ -18,7 +19,7 @@ def build(force=False):
     """Compile oracle.c -> liboracle.so with gcc (recipe: oracle/Makefile)."""
     src = os.path.join(_HERE, "oracle.c")
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB)], stdout=subprocess.DEVNULL)
     return _LIB
 
 
