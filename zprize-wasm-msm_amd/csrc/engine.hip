@@ -220,7 +220,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_count, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_bins, ORDER_KEYS * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_bins, 2 * ORDER_KEYS * 4)) return rc;   // key populations, then the per-key cursors
     if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nv * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
     uint32_t* count = (uint32_t*)sl->d_count.p;
@@ -305,7 +305,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 #undef MSM_TILE_HIST
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. bin starts
-        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur, bins, (uint32_t)ORDER_KEYS);
+        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
         sl->binhist_zero = sl->d_binhist.p;
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
@@ -373,8 +373,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             else k_big_scatter<uint2><<<big_grid, SORT_BLOCK, big_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
         }
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
-        k_order_scan<<<1, 1024, 0, st>>>(bins);
-        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, order);
+        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
     // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation).

@@ -354,11 +354,20 @@ constexpr size_t tile_scatter_lds(int T, int GW, int BLOCK) {
     return (size_t)GW * T * sizeof(E) + (size_t)2 * GW * COARSE_MAX * 4 + (size_t)(BLOCK / 64) * 4 + (size_t)GW * T * 2;
 }
 
+// Ordering of buckets by population (descending), counting sort on min(count, ORDER_BINS-1).
+constexpr int ORDER_BINS = 1024;
+// Sort key: (bucket >= split ? 1 : 0, size class).  With split < nb the order array comes out as
+// [buckets of the first window group by falling population][buckets of the second group by falling population],
+// which lets the engine accumulate and reduce the two groups in two overlapping waves (see submit_msm).
+constexpr int ORDER_KEYS = 2 * ORDER_BINS;
+MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split) {
+    return (b >= split ? (uint32_t)ORDER_BINS : 0u) + ((ORDER_BINS - 1) - min(cnt, (uint32_t)(ORDER_BINS - 1)));   // big buckets first
+}
 // ------------------------------------------------------------------------------------------
 // fine sort of one (window, coarse bin) span: bucket count / offset tables and the index lists grouped by bucket
 // ------------------------------------------------------------------------------------------
-constexpr int FINE_ITEMS = 36;                         // entries per lane held in registers
-constexpr int FINE_CAP = FINE_ITEMS * SORT_BLOCK;      // 9216: spans up to this size are read once by one workgroup
+constexpr int FINE_ITEMS = 37;                         // entries per lane held in registers: nine 16-byte vectors + one head / tail entry
+constexpr int FINE_CAP = 36 * SORT_BLOCK;              // 9216: spans up to this size are read once by one workgroup
 
 // LONG_HERE: spans beyond FINE_CAP are handled by this workgroup too (chunk by chunk: histogram sweep, then chunk-wise counting
 // sort with stores by bucket runs) -- the form launched when no long span is expected, so that an unexpected one (adversarial
@@ -409,28 +418,79 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
     __syncthreads();
     E e[FINE_ITEMS];
     uint32_t rank[FINE_ITEMS];
+    // Slot s of this lane's k-th entry.  4-byte entries are read and written as 16-byte vectors (a quarter of the memory
+    // instructions; 4-byte accesses run at a fraction of the 16-byte rate): the span is cut at the 16-byte boundaries of its global
+    // address into a head of < 4 entries, whole vectors, and a tail of < 4; lane t takes vectors t, t + 256, ... and entry k of a lane
+    // is word k % 4 of its vector k / 4.  The < 8 head / tail entries ride in the last register slot of lanes 0..7.
+    constexpr bool VEC = sizeof(E) == 4;
+    constexpr int NV = (FINE_ITEMS - 1) / 4;    // vectors per lane (the last slot is the head / tail entry)
+    uint32_t head = 0, nvec = 0, ntail = 0;
+    if constexpr (VEC) {
+        head = min(span, (4u - (start & 3u)) & 3u);
+        nvec = (span - head) >> 2;
+        ntail = span - head - 4u * nvec;
+    }
+    auto slot_of = [&](int k) -> uint32_t {      // position inside the span, or 0xffffffff when the slot is empty
+        if constexpr (VEC) {
+            if (k == FINE_ITEMS - 1) {
+                if (t < head) return t;
+                if (t >= 4 && t - 4 < ntail) return head + 4u * nvec + (t - 4);
+                return 0xffffffffu;
+            }
+            if (k >= 4 * NV) return 0xffffffffu;
+            const uint32_t v = (uint32_t)(k >> 2) * SORT_BLOCK + t;
+            return v < nvec ? head + 4u * v + (uint32_t)(k & 3) : 0xffffffffu;
+        } else {
+            const uint32_t s2 = (uint32_t)k * SORT_BLOCK + t;
+            return s2 < span ? s2 : 0xffffffffu;
+        }
+    };
+    if constexpr (VEC) {
+        static_assert(NV * 4 * SORT_BLOCK + 8 >= FINE_CAP, "the register slots cover a span of FINE_CAP entries");
+        const uint4* vp = reinterpret_cast<const uint4*>(tmp + start + head);
 #pragma unroll
-    for (int k = 0; k < FINE_ITEMS; ++k) {
-        const uint32_t s = k * SORT_BLOCK + t;
-        if (s < span) e[k] = tmp[start + s];
+        for (int j = 0; j < NV; ++j) {
+            const uint32_t v = (uint32_t)j * SORT_BLOCK + t;
+            if (v < nvec) {
+                const uint4 q = vp[v];
+                e[4 * j] = q.x;
+                e[4 * j + 1] = q.y;
+                e[4 * j + 2] = q.z;
+                e[4 * j + 3] = q.w;
+            }
+        }
+        const uint32_t sx = slot_of(FINE_ITEMS - 1);
+        if (sx != 0xffffffffu) e[FINE_ITEMS - 1] = tmp[start + sx];
+    } else {
+#pragma unroll
+        for (int k = 0; k < FINE_ITEMS; ++k) {
+            const uint32_t s2 = slot_of(k);
+            if (s2 != 0xffffffffu) e[k] = tmp[start + s2];
+        }
     }
 #pragma unroll
-    for (int k = 0; k < FINE_ITEMS; ++k) {
-        const uint32_t s = k * SORT_BLOCK + t;
-        if (s < span) rank[k] = atomicAdd(&h[entry_fine(e[k], sg.idxbits)], 1u);
-    }
+    for (int k = 0; k < FINE_ITEMS; ++k)
+        if (slot_of(k) != 0xffffffffu) rank[k] = atomicAdd(&h[entry_fine(e[k], sg.idxbits)], 1u);
     __syncthreads();
     for (uint32_t i = t; i < nf; i += SORT_BLOCK) count[gb0 + i] = h[i];
     __syncthreads();
     block_exclusive_scan(h, nf, wsum);
     for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
 #pragma unroll
-    for (int k = 0; k < FINE_ITEMS; ++k) {
-        const uint32_t s = k * SORT_BLOCK + t;
-        if (s < span) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits);
-    }
+    for (int k = 0; k < FINE_ITEMS; ++k)
+        if (slot_of(k) != 0xffffffffu) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits);
     __syncthreads();
-    for (uint32_t s = t; s < span; s += SORT_BLOCK) sorted[start + s] = out[s];
+    if constexpr (VEC) {
+        uint4* op = reinterpret_cast<uint4*>(sorted + start + head);
+        for (uint32_t v = t; v < nvec; v += SORT_BLOCK) {
+            const uint32_t* src = out + head + 4u * v;
+            op[v] = make_uint4(src[0], src[1], src[2], src[3]);
+        }
+        if (t < head) sorted[start + t] = out[t];
+        if (t >= 4 && t - 4 < ntail) sorted[start + head + 4u * nvec + (t - 4)] = out[head + 4u * nvec + (t - 4)];
+    } else {
+        for (uint32_t s2 = t; s2 < span; s2 += SORT_BLOCK) sorted[start + s2] = out[s2];
+    }
 }
 
 // ---- spans beyond FINE_CAP (large n; the few dense bins of a partly used top window; adversarial scalars): cut into chunks of
@@ -579,63 +639,56 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_scatter(const E* __restrict_
 // ------------------------------------------------------------------------------------------
 // ordering of the buckets by population
 // ------------------------------------------------------------------------------------------
-// Ordering of buckets by population (descending), counting sort on min(count, ORDER_BINS-1).
-constexpr int ORDER_BINS = 1024;
-// Sort key: (bucket >= split ? 1 : 0, size class).  With split < nb the order array comes out as
-// [buckets of the first window group by falling population][buckets of the second group by falling population],
-// which lets the engine accumulate and reduce the two groups in two overlapping waves (see submit_msm).
-constexpr int ORDER_KEYS = 2 * ORDER_BINS;
-MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split) {
-    return (b >= split ? (uint32_t)ORDER_BINS : 0u) + ((ORDER_BINS - 1) - min(cnt, (uint32_t)(ORDER_BINS - 1)));   // big buckets first
-}
-__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ bins) {
+// obins[k] += number of buckets with ordering key k.  (Tallying the keys inside the fine-sort kernels, which hold the populations in
+// LDS, was tried: the extra barriers and the 2048-word scratch cost k_fine_small more than this 8-us pass saves.)
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ obins) {
     __shared__ uint32_t h[ORDER_KEYS];
     h[threadIdx.x] = 0;
     h[threadIdx.x + ORDER_BINS] = 0;
     __syncthreads();
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) atomicAdd(&h[order_key(b, count[b], split)], 1u);
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&bins[threadIdx.x], h[threadIdx.x]);
-    if (h[threadIdx.x + ORDER_BINS]) atomicAdd(&bins[threadIdx.x + ORDER_BINS], h[threadIdx.x + ORDER_BINS]);
+    if (h[threadIdx.x]) atomicAdd(&obins[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x + ORDER_BINS]) atomicAdd(&obins[threadIdx.x + ORDER_BINS], h[threadIdx.x + ORDER_BINS]);
 }
-__global__ void __launch_bounds__(1024) k_order_scan(uint32_t* __restrict__ bins) {
-    __shared__ uint32_t buf[ORDER_BINS];
-    // two keys per lane (2t, 2t+1), then a scan over the pair sums
-    uint32_t a = bins[2 * threadIdx.x], b = bins[2 * threadIdx.x + 1];
-    uint32_t v = a + b;
-    buf[threadIdx.x] = v;
-    __syncthreads();
-    for (int d = 1; d < ORDER_BINS; d <<= 1) {
-        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
-        __syncthreads();
-        buf[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t excl = buf[threadIdx.x] - v;
-    bins[2 * threadIdx.x] = excl;
-    bins[2 * threadIdx.x + 1] = excl + a;
-}
-__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ bins,
-                                                         uint32_t* __restrict__ order) {
+// order[]: the buckets by falling population.  obins[k] = number of buckets with key k (k_order_hist); every
+// workgroup scans those 2048 counters itself (an exclusive prefix: where each key's buckets start), counts the keys of its own span of
+// buckets in LDS, reserves their places with one atomic per key on ocur[k], and writes its buckets there.
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, const uint32_t* __restrict__ obins,
+                                                         uint32_t* __restrict__ ocur, uint32_t* __restrict__ order) {
     __shared__ uint32_t h[ORDER_KEYS];
     __shared__ uint32_t basep[ORDER_KEYS];
-    h[threadIdx.x] = 0;
-    h[threadIdx.x + ORDER_BINS] = 0;
+    __shared__ uint32_t wsum[16];
+    const uint32_t t = threadIdx.x;
+    // exclusive prefix of the key populations: two keys per lane (2t, 2t+1)
+    const uint32_t a = obins[2 * t], b = obins[2 * t + 1], v = a + b;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(t & 63u) >= d) incl += o;
+    }
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+    h[t] = 0;
+    h[t + ORDER_BINS] = 0;
     __syncthreads();
+    uint32_t excl = incl - v;
+    for (uint32_t q = 0; q < (t >> 6); ++q) excl += wsum[q];
     // each workgroup owns a contiguous span of buckets
     uint32_t per = (nb + gridDim.x - 1) / gridDim.x;
     uint32_t lo = blockIdx.x * per, hi = min(nb, lo + per);
-    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) atomicAdd(&h[order_key(b, count[b], split)], 1u);
+    for (uint32_t bk = lo + t; bk < hi; bk += blockDim.x) atomicAdd(&h[order_key(bk, count[bk], split)], 1u);
     __syncthreads();
-    for (uint32_t k = threadIdx.x; k < ORDER_KEYS; k += ORDER_BINS) basep[k] = h[k] ? atomicAdd(&bins[k], h[k]) : 0;
+    basep[2 * t] = excl + (h[2 * t] ? atomicAdd(&ocur[2 * t], h[2 * t]) : 0u);
+    basep[2 * t + 1] = excl + a + (h[2 * t + 1] ? atomicAdd(&ocur[2 * t + 1], h[2 * t + 1]) : 0u);
     __syncthreads();
-    h[threadIdx.x] = 0;
-    h[threadIdx.x + ORDER_BINS] = 0;
+    h[t] = 0;
+    h[t + ORDER_BINS] = 0;
     __syncthreads();
-    for (uint32_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
-        uint32_t key = order_key(b, count[b], split);
+    for (uint32_t bk = lo + t; bk < hi; bk += blockDim.x) {
+        uint32_t key = order_key(bk, count[bk], split);
         uint32_t p = basep[key] + atomicAdd(&h[key], 1u);
-        order[p] = b;
+        order[p] = bk;
     }
 }
 
