@@ -1,6 +1,6 @@
 // bucket_kernels.hpp -- the two ALU-bound kernels of the engine (bucket accumulation, bucket
 // reduction) and their launchers.  Each coordinate field gets its own translation unit
-// (bucket_*.hip) so the heavy instantiations compile in parallel; msm_engine.hip only sees the
+// (bucket_*.hip) so the heavy instantiations compile in parallel; engine.hip only sees the
 // launcher declarations.
 #pragma once
 #include "engine_common.hpp"

@@ -63,18 +63,32 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
 }
 
-static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced) {
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards) {
     uint32_t c;
     if (forced) {
         c = forced;
+    } else if (n >= (1u << 23)) {
+        // From n = 2^23 the additions saved by fewer, wider windows (14 windows of 19 bits / 13 of 20 over a 255-bit scalar instead of
+        // 16 of 16 bits) outweigh the 8-16 times larger bucket arrays and their reduction (profiles/r02_sweep_window_bits_large_n.txt:
+        // n = 2^24 39.0 ms at c = 19 against 42.7 at c = 16, n = 2^26 145.3 ms at c = 20 against 177.3; the reference widens its window
+        // with n too, build_multiexp.js:275-280).  A sharded call is as slow as its busiest rank, which owns ceil(W / nshards) windows:
+        // 13 windows over 8 ranks are 2 + 1, 16 windows are 2 + 2 -- so the choice minimises
+        //     (windows of the busiest rank) x (n bucket additions + 2^(c-1) buckets x the cost of reducing one, ~6 additions' worth).
+        uint64_t best = ~0ull;
+        c = 16;
+        for (uint32_t cand : {16u, 19u, 20u}) {
+            if (cand > nbits) continue;
+            const uint32_t w = (nbits + cand - 1) / cand;   // windows that receive scalar bits (a further carry-only window is negligible)
+            const uint64_t cost = (uint64_t)((w + nshards - 1) / nshards) * ((uint64_t)n + 6ull * (1ull << (cand - 1)));
+            if (cost < best) {
+                best = cost;
+                c = cand;
+            }
+        }
     } else {
-        // measured on MI355X (profiles/r01_sweep_window_bits*.log, r02_sweep_window_bits_large_n.txt): the bucket reduction costs
-        // about the same whatever n is (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below
-        // that, 8 bits.  From n = 2^23 the additions saved by fewer, wider windows (14 windows of 19 bits / 13 of 20 over a 255-bit
-        // scalar instead of 16 of 16 bits) outweigh the 8-16 times larger bucket arrays and their reduction: n = 2^24 39.0 ms
-        // (c = 19) against 42.7, n = 2^26 145.3 ms (c = 20) against 177.3.  The reference widens its window with n too
-        // (build_multiexp.js:275-280).
-        c = n >= (1u << 25) ? 20 : n >= (1u << 23) ? 19 : n >= 4096 ? 16 : 8;
+        // measured on MI355X (profiles/r01_sweep_window_bits*.log): the bucket reduction costs about the same whatever n is
+        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits
+        c = n >= 4096 ? 16 : 8;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
@@ -114,7 +128,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // both measures; calls with a full-size accumulation were 3-8 % slower on S2, hence two streams)
     bool small_est;
     {
-        const uint32_t c0 = pick_window_bits(a.n, a.nbits, ctx->force_c), w0 = a.nbits / c0 + 1;
+        const uint32_t c0 = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards), w0 = a.nbits / c0 + 1;
         small_est = (uint64_t)((w0 + a.nshards - 1) / a.nshards) << (c0 - 1) < 2u * 1024u * 64u;
     }
     if (small_est && !ctx->stream_s2) {
@@ -155,7 +169,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.scalar_size = a.scalar_size;
     g.bit_lo = a.bit_lo;
     g.nbits = a.nbits;
-    g.c = pick_window_bits(a.n, a.nbits, ctx->force_c);
+    g.c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards);
     g.W = a.nbits / g.c + 1;
     g.half = 1u << (g.c - 1);
     g.shard = a.shard;
@@ -163,7 +177,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // GLV path -- only for callers that vouch for their bases (flag MSM_AMD_BASES_IN_SUBGROUP, or option "glv" = 2): k*P = k1*P + k2*phi(P)
     // with k reduced mod r holds in the order-r subgroup only, while the reference's multiexp is plain integer arithmetic, exact for
     // ANY point of the curve (G1 has a ~2^126 cofactor).  Without the flag the engine keeps the reference's semantics.
-    // 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_digits_glv).  Same number of bucket
+    // 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_glv_halves).  Same number of bucket
     // additions, half the buckets.  It pays where the bucket reduction dominates (n <= 2^17: 8-15 % per call); from 2^18 up
     // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
     // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2

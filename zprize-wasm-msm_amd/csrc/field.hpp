@@ -63,7 +63,7 @@ MSM_HD void mac_s(uint64_t& lo, uint32_t& hi, uint32_t a, uint32_t b) {
 }
 
 // INL = true: multiplies are expanded inline at every use; INL = false: one out-of-line body per translation unit
-// (small code) -- what every kernel of msm_engine.hip uses.  The bucket kernels no longer compute in this packed
+// (small code) -- what the kernels of conv_kernels.hip and fft_kernels.hip use.  The bucket kernels no longer compute in this packed
 // representation at all (field_u.hpp); Fp<P, true> survives as the tag under which their G1 instantiations are named.
 // Both flavours have the same layout and value semantics.
 template <class P, bool INL = false>
