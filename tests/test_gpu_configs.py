@@ -241,6 +241,38 @@ def test_blocked_fft_building_blocks_match_the_reference(eng, orc):
         assert buf == C.frm_fft(b"".join(x))
 
 
+@pytest.mark.parametrize("curve", ["bls12381", "bn128"])
+def test_lane_pair_reduction_matches_oracle(eng, orc, curve):
+    """Option reduce_pair = 1: the G1 bucket reduction with every point split over a lane pair (XYZZH: even lane (x, zz), odd lane
+    (y, zzz); eight product rounds per addition).  Random inputs, repeated points (the doubling branch of the pair addition: equal
+    buckets meet in the running sums), P and -P, infinity among the bases, several window sizes and L."""
+    n = 6000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, 1)
+    asz = 2 * O.fsz
+    bases, scalars = gu.random_case(curve, 1, f"gpu:pairred:{curve}", n)
+    bases = bytearray(bases)
+    bases[asz * 7:asz * 8] = bytes(asz)                                   # affine infinity
+    for i in range(100, 200):                                             # one point a hundred times ...
+        bases[asz * i:asz * (i + 1)] = bases[asz * 100:asz * 101]
+    bases = bytes(bases)
+    sc = bytearray(scalars)
+    for i in range(100, 200):                                             # ... with scalars 1, 2, 3, ...: neighbouring buckets hold equal sums
+        sc[32 * i:32 * (i + 1)] = (i - 99).to_bytes(32, "little")
+    scalars = bytes(sc)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    try:
+        eng.set_option("reduce_pair", 1)
+        for c, L in ((0, 0), (16, 1), (16, 32), (9, 4), (4, 0)):
+            eng.set_window_bits(c)
+            eng.set_option("reduce_l", L)
+            assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp, (c, L)
+    finally:
+        eng.set_option("reduce_pair", 0)
+        eng.set_option("reduce_l", 0)
+        eng.set_window_bits(0)
+
+
 def test_reduce_l_must_be_a_power_of_two(eng):
     """The LDS trees of the bucket reduction halve the lane count: a lane count that is not a power of two would drop a partial
     sum (reduce_l = 200 at c = 16 gave 164 lanes).  The option refuses such values instead."""

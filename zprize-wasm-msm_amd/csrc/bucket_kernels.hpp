@@ -292,6 +292,69 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
 }
 
 
+// The same reduction for G1 with every point split over a lane pair (XYZZH, curve_u.hpp): the dependent chain of a lane is 8 instead
+// of 14 field products per addition and its live state halves (two such waves fit a SIMD beside an accumulation wave).  Logical lane
+// lt = threadIdx / 2 owns L consecutive buckets exactly as above; `rblock` counts logical lanes.
+template <class F>
+__global__ void __launch_bounds__(512) k_bucket_reduce_pair(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t lanes_per_window,
+                                                             uint32_t wgs_per_window, uint8_t* __restrict__ partials, const uint32_t* __restrict__ offset,
+                                                             const uint32_t* __restrict__ count, uint32_t gb0, uint32_t NB) {
+    using H = XYZZH<typename F::Params>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    H* sh = reinterpret_cast<H*>(smem);
+    const uint32_t lt = threadIdx.x >> 1, nlt = blockDim.x >> 1;
+    const uint32_t w = blockIdx.x / wgs_per_window, wg = blockIdx.x % wgs_per_window;
+    {
+        const uint32_t gb = gb0 + w * half;
+        const uint32_t beg = offset[gb];
+        const uint32_t end = gb + half < NB ? offset[gb + half] : offset[NB - 1] + count[NB - 1];
+        if (beg == end) {   // nothing was scattered into this window: its sum is infinity
+            if (lt == 0) H::inf().to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
+            return;
+        }
+    }
+    const uint32_t t = wg * nlt + lt;
+    H res = H::inf();
+    if (t < lanes_per_window) {   // both lanes of a pair share t
+        const uint32_t base = t * L;
+        H run = H::inf(), sum = H::inf();
+        for (int j = (int)L - 1; j >= 0; --j) {
+            if (base + j < half) run = H::add(run, H::load_bucket(buckets + ((size_t)w * half + base + j) * sizeof(BU<F>)));
+            sum = H::add(sum, run);
+        }
+        H m = H::inf();   // res = sum + base * run
+        if (base != 0) {
+            const int top = 31 - __clz(base);
+            for (int bit = top; bit >= 0; --bit) {
+                m = H::dbl(m);
+                if ((base >> bit) & 1u) m = H::add(m, run);
+            }
+        }
+        res = H::add(sum, m);
+    }
+    sh[threadIdx.x] = res;
+    __syncthreads();
+    for (uint32_t d = nlt / 2; d > 0; d >>= 1) {
+        if (lt < d) {
+            const H a = sh[threadIdx.x], bb = sh[threadIdx.x + 2 * d];
+            sh[threadIdx.x] = H::add(a, bb);
+        }
+        __syncthreads();
+    }
+    if (lt == 0) sh[threadIdx.x].to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
+}
+template <class F>
+void launch_bucket_reduce_pair(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
+                               uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
+                               uint32_t gb0, uint32_t NB) {
+    static_assert(2 * sizeof(XYZZH<typename F::Params>) == sizeof(BU<F>), "a lane pair holds one bucket");
+    k_bucket_reduce_pair<F><<<nparts, rblock * 2, (size_t)rblock * sizeof(BU<F>), st>>>(buckets, half, L, lanes_per_window, wgs_per_window, partials, offset,
+                                                                                       count, gb0, NB);
+}
+#define MSM_INSTANTIATE_REDUCE_PAIR(F)                                                                                                       \
+    template void launch_bucket_reduce_pair<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*, \
+                                               const uint32_t*, const uint32_t*, uint32_t, uint32_t);
+
 // The accumulation kernel proper and the rest (tail kernels, reduction) are instantiated in different translation units:
 // the former is compiled with MSM_U_CHAINED_MADS (field_u.hpp), the latter -- kernels that run few waves -- without.
 template <class F, int VARIANT>

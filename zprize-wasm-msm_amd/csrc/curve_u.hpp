@@ -329,6 +329,122 @@ struct XYZZU {
     }
 };
 
+// ---- an XYZZ point of a G1 kind split over a LANE PAIR: the even lane holds (x, zz), the odd lane (y, zzz) --------------------
+// Used by the bucket reduction, which is a chain of ~40 dependent full additions on few waves: one lane per point runs the 14
+// field products of an addition (add-2008-s) one after the other with both operands live (256 registers).  The products of an
+// addition are two nearly independent halves -- the x side (U1, U2, P, PP, PPP, Q, X3, ZZ3) and the y side (S1, S2, R, RR,
+// S1*PPP, Y3, ZZZ3) -- so a pair of lanes runs them side by side: EIGHT product rounds instead of fourteen, half the live state
+// per lane, four DPP exchanges (quad_perm [1,0,3,2], as the Fp2 kernels use).  Both lanes execute one instruction stream; where
+// the two sides multiply different things the operands are picked by lane parity (pair_select).  Round by round (E | O):
+//   m1 = a.c0*b.c1    U1 = X1 ZZ2        | S1 = Y1 ZZZ2
+//   m2 = b.c0*a.c1    U2 = X2 ZZ1        | S2 = Y2 ZZZ1          d = m2 - m1:  P | R
+//   sq = d^2          PP                 | RR                    (both zero <=> the same point: doubling)
+//   t  = a.c1*b.c1    ZZ1 ZZ2            | ZZZ1 ZZZ2             exchange d, sq: both lanes now hold P, PP; E also RR
+//   ppp = P*PP        (both lanes)
+//   r6                Q = U1 PP          | ZZZ3 = t PPP
+//   r7                ZZ3 = t PP         | S1 PPP                E: X3 = RR - PPP - 2Q; exchange Q - X3
+//   r8                (idle)             | Y3 = R (Q - X3) - S1 PPP
+// Doubling (dbl-2008-s-1) the same way in five rounds.  Case analysis as XYZZU::add (build_curve_jacobian_a0.js:583-629); every
+// predicate is reduced over the pair, so both lanes always take the same path.
+template <class P>
+struct XYZZH {
+    using K = UG1<P>;
+    using C0 = typename K::L;   // x | y (a stored y, FuM<3>, fits the looser bounds of a stored x)
+    using C1 = typename K::M;   // zz | zzz
+    C0 c0;
+    C1 c1;
+
+    MSM_D static XYZZH inf() {
+        XYZZH r;
+        r.c0 = pair_parity() ? fstore<C0>(K::one()) : K::template zero<C0>();   // (x, y) = (0, 1)
+        r.c1 = K::template zero<C1>();
+        return r;
+    }
+    MSM_D bool is_inf() const {
+        const uint32_t z = fis_zero(c1) ? 1u : 0u;   // zz and zzz vanish together
+        return (z & pair_xchg(z)) != 0;
+    }
+    // this lane's half of bucket `b` as the accumulation kernels store it (XYZZU<UG1>: x, y, zz, zzz of NL words each)
+    MSM_D static XYZZH load_bucket(const uint8_t* __restrict__ b) {
+        constexpr int NL = UC<P>::NL;
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(b) + pair_parity() * NL;
+        XYZZH r;
+#pragma unroll
+        for (int i = 0; i < NL; i += 2) {   // NL-word coordinates are 8-byte aligned (NL even) or handled word-wise (NL odd)
+            if constexpr (NL % 2 == 0) {
+                const uint2 q0 = *reinterpret_cast<const uint2*>(w + i), q1 = *reinterpret_cast<const uint2*>(w + 2 * NL + i);
+                r.c0.v[i] = q0.x;
+                r.c0.v[i + 1] = q0.y;
+                r.c1.v[i] = q1.x;
+                r.c1.v[i + 1] = q1.y;
+            } else {
+                r.c0.v[i] = w[i];
+                r.c1.v[i] = w[2 * NL + i];
+                if (i + 1 < NL) {
+                    r.c0.v[i + 1] = w[i + 1];
+                    r.c1.v[i + 1] = w[2 * NL + i + 1];
+                }
+            }
+        }
+        return r;
+    }
+    MSM_D static XYZZH dbl(const XYZZH& p) {
+        if (p.is_inf()) return p;
+        const bool odd = pair_parity() != 0;
+        auto u = fdbl(p.c0);                                        // O: U = 2y
+        auto base = pair_select(p.c0, u, odd);                      // E: x | O: U
+        auto s1 = fsqr(base);                                       // E: XX | O: V
+        auto os1 = pair_xchg(s1);                                   // E: V | O: XX
+        auto vv = pair_select(os1, s1, odd);                        // V on both lanes
+        auto xx = pair_select(s1, os1, odd);                        // XX on both lanes
+        auto r2 = fmul(base, vv);                                   // E: S = x V | O: W = U V
+        auto Mm = fprep(fadd(fdbl(xx), xx));                        // M = 3 XX on both lanes
+        auto r3 = fmul(pair_select(Mm, r2, odd), pair_select(Mm, p.c1, odd));   // E: M^2 | O: ZZZ3 = W zzz
+        auto x3 = fnorm(fsub(r3, fdbl(r2)));                        // E: X3 = M^2 - 2S
+        auto r4 = fmul(pair_select(vv, r2, odd), pair_select(p.c1, p.c0, odd)); // E: ZZ3 = V zz | O: W y
+        auto ow = pair_xchg(fnorm(fsub(r2, x3)));                   // O: S - X3
+        auto y3 = fnorm(fsub(fmul(Mm, ow), r4));                    // O: Y3 = M (S - X3) - W y
+        XYZZH r;
+        r.c0 = fstore<C0>(pair_select(x3, y3, odd));
+        r.c1 = fstore<C1>(pair_select(r4, r3, odd));
+        return r;
+    }
+    MSM_D static XYZZH add(const XYZZH& a, const XYZZH& b) {
+        if (a.is_inf()) return b;
+        if (b.is_inf()) return a;
+        const bool odd = pair_parity() != 0;
+        auto m1 = fmul(a.c0, b.c1);                                 // E: U1 | O: S1
+        auto m2 = fmul(b.c0, a.c1);                                 // E: U2 | O: S2
+        auto d = fprep(fsub(m2, m1));                               // E: P  | O: R
+        auto sq = fsqr(d);                                          // E: PP | O: RR
+        {
+            const uint32_t z = fis_zero(sq) ? 1u : 0u;
+            if (z & pair_xchg(z)) return dbl(a);                    // P = R = 0: the same point
+        }
+        auto t = fmul(a.c1, b.c1);                                  // E: ZZ1 ZZ2 | O: ZZZ1 ZZZ2
+        auto od = pair_xchg(d);
+        auto osq = pair_xchg(sq);                                   // E: RR | O: PP
+        auto pd = pair_select(d, od, odd);                          // P on both lanes
+        auto pp = pair_select(sq, osq, odd);                        // PP on both lanes
+        auto ppp = fmul(pd, pp);                                    // PPP on both lanes
+        auto r6 = fmul(pair_select(m1, t, odd), pair_select(pp, ppp, odd));   // E: Q = U1 PP | O: ZZZ3 = t PPP
+        auto r7 = fmul(pair_select(t, m1, odd), pair_select(pp, ppp, odd));   // E: ZZ3 = t PP | O: S1 PPP
+        auto x3 = fnorm(fsub(osq, fadd(ppp, fdbl(r6))));            // E: X3 = RR - PPP - 2Q
+        auto ow = pair_xchg(fnorm(fsub(r6, x3)));                   // O: Q - X3
+        auto y3 = fnorm(fsub(fmul(d, ow), r7));                     // O: Y3 = R (Q - X3) - S1 PPP
+        XYZZH r;
+        r.c0 = fstore<C0>(pair_select(x3, y3, odd));
+        r.c1 = fstore<C1>(pair_select(r7, r6, odd));
+        return r;
+    }
+    // canonical packed image XYZZ<Packed>: this lane writes its two coordinates
+    MSM_D void to_packed(uint32_t* w) const {
+        const uint32_t par = pair_parity();
+        K::store(w + par * K::WORDS, c0);
+        K::store(w + (2 + par) * K::WORDS, c1);
+    }
+};
+
 #endif  // __HIPCC__
 
 }  // namespace msm

@@ -38,6 +38,10 @@ template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
                           uint32_t gb0, uint32_t NB);
+template <class F>
+void launch_bucket_reduce_pair(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
+                               uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
+                               uint32_t gb0, uint32_t NB);   // G1 only: every point of the reduction on a lane pair (XYZZH, curve_u.hpp)
 // field flavour used inside the bucket kernels: G1 fields expand their multiplies inline
 template <class F>
 size_t bucket_bytes();   // bytes of one bucket in HBM (the bucket kernels keep their own representation, curve_u.hpp)
@@ -505,12 +509,23 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     uint8_t* partials = (uint8_t*)sl->d_partials.p;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
-    launch_bucket_reduce<FK>(sb, nparts0, p0.rblock, buckets, g.half, p0.L, p0.lanes, p0.wgs, partials, offset, count, 0, NB);
+    // G1, option "reduce_pair" = 1: the reduction runs every addition on a lane pair (8 product rounds instead of 14, 178 instead of
+    // 256 registers).  Measured and left off (profiles/r02_reduce_lane_pair_tried.txt): the same time one call at a time, 4-5 % slower
+    // when calls are pipelined (2 x 4500 instead of 7000 instructions per addition)
+    auto reduce = [&](hipStream_t s_, uint32_t np, const Plan& pl, const uint8_t* bk, uint8_t* part, uint32_t gb0_) {
+        if constexpr (KernelField<F>::chained_variant) {
+            if (ctx->reduce_pair) {
+                launch_bucket_reduce_pair<FK>(s_, np, pl.rblock, bk, g.half, pl.L, pl.lanes, pl.wgs, part, offset, count, gb0_, NB);
+                return;
+            }
+        }
+        launch_bucket_reduce<FK>(s_, np, pl.rblock, bk, g.half, pl.L, pl.lanes, pl.wgs, part, offset, count, gb0_, NB);
+    };
+    reduce(sb, nparts0, p0, buckets, partials, 0);
     if (nparts1) {
         hipStream_t sc = sl->stream_c;
         HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
-        launch_bucket_reduce<FK>(sc, nparts1, p1.rblock, buckets + (size_t)split * BSZ, g.half, p1.L, p1.lanes, p1.wgs, partials + (size_t)nparts0 * XSZ, offset,
-                                 count, split, NB);
+        reduce(sc, nparts1, p1, buckets + (size_t)split * BSZ, partials + (size_t)nparts0 * XSZ, split);
         HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
         HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
     }
@@ -963,6 +978,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         return 0;
     }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
+    if (!strcmp(name, "reduce_pair")) { ctx->reduce_pair = value != 0; return 0; }
     if (!strcmp(name, "sort_big")) { ctx->sort_big = value > 2 ? 0 : (int)value; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split2")) { ctx->no_split2 = value == 0; return 0; }
