@@ -413,14 +413,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // (one workgroup iteration per over-long bucket: 32768 of them cost 40 ms at n = 2^24, profiles/r02_sweep_c_first.txt).
     uint32_t seg = ctx->force_seg ? ctx->force_seg : std::max(32u, mean + 8u * (uint32_t)std::ceil(std::sqrt((double)mean)) + 8u);
     if (!ctx->force_seg) {
+        // Buckets that are denser than the mean without being pathological: (a) scalars one bit shorter than their declared width
+        // (a 254-bit group order in 32 bytes) fill the top window's buckets twice as densely; (b) a top window that the scalar bits
+        // only partly fill (c = 20 over 256 bits: 16 of 20) uses 2^tb of its buckets, 2^(c-1-tb) times denser -- twice that when the
+        // top bit is clear.  Such buckets are many, equally long, and start first (population order): they are lanes like any other,
+        // as long as their chain stays below the launch's own duration (cap: 80 % of a lane slot's share of the additions).
+        auto bound = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d + 8u * (uint64_t)std::ceil(std::sqrt((double)d)) + 8u, 1u << 24); };
+        uint32_t seg_hi = bound(2ull * mean);
         const uint32_t tb = g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u;   // scalar bits in the top window
-        if (tb >= 12 && tb < g.c - 1) {
-            // twice the nominal density: scalars below a 255-bit group order leave the top bit clear
-            const uint32_t dense = 2u * (uint32_t)(((uint64_t)nv + (1ull << tb) - 1) >> tb);
-            const uint32_t seg_hi = dense + 8u * (uint32_t)std::ceil(std::sqrt((double)dense)) + 8u;
-            const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nv) / 200000u, 1u << 20);   // ~ a fifth of a lane's share of the launch
-            seg = std::max(seg, std::min(seg_hi, cap));
-        }
+        if (tb >= 12 && tb < g.c - 1) seg_hi = std::max(seg_hi, bound(2ull * (((uint64_t)nv + (1ull << tb) - 1) >> tb)));
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nv) / 245760u, 1u << 20);
+        seg = std::max(seg, std::min(seg_hi, cap));
     }
     const size_t max_segs = (size_t)g.Wl * nv / seg + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
