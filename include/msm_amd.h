@@ -80,8 +80,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * "glv" (0 never | 1 (default) where it pays AND the call carries MSM_AMD_BASES_IN_SUBGROUP | 2 whenever it applies, the option itself
  * being the caller's word that the bases lie in the order-r subgroup: the GLV schedule of BLS12-381 G1),
  * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice),
- * "split2" (0 = never give a bucket two lanes; default 1: G1 launches with few buckets do), "split2_nb" (bucket count below
- * which they do, default 131072 = two waves per SIMD). */
+ * "split2" (0 = one lane per bucket always; default 1: G1 launches with few buckets cut their buckets into slices, one lane each), "splitk" (lanes per
+ * bucket of such a launch: 0 = chosen per launch, 1..64 forced), "splitk_lanes" (the lane count that choice
+ * brings a launch with few buckets to, default 327680). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 /* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
  * hardware queue (their kernels serialise).  HIP maps streams onto hardware queues in creation order across the whole process, and

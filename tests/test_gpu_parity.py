@@ -293,30 +293,35 @@ def test_split_window_groups(eng, orc):
 
 
 @pytest.mark.parametrize("curve", ["bls12381", "bn128"])
-def test_two_lanes_per_bucket(eng, orc, curve):
-    """Launches with few, well-filled buckets give every bucket two lanes (k_accumulate_split2): same bytes as with one lane,
-    with odd and single-entry buckets (3001 entries over 2^7 buckets, 101 over 2^2), with long buckets cut into segments,
-    and with equal partial sums meeting at the join of the two halves (P + P)."""
+def test_several_lanes_per_bucket(eng, orc, curve):
+    """Launches with few, well-filled buckets give every bucket several lanes (k_accumulate_slices + k_join_slices): same bytes as
+    with one lane, with odd and single-entry buckets (3001 entries over 2^7 buckets, 101 over 2^2), with long buckets cut into
+    segments, and with equal partial sums meeting at the join of the slices (P + P)."""
     group = 1
     C = eng.curve(curve)
     O = orc.Oracle(curve, group)
     A = C.affine_bytes(group)
     try:
-        for n, c, seg in [(3001, 8, 0), (101, 3, 0), (1500, 6, 5), (2048, 4, 0)]:   # mean population >= 16: the two-lane kernel applies
+        for n, c, seg in [(3001, 8, 0), (101, 3, 0), (1500, 6, 5), (2048, 4, 0)]:   # mean population >= 16: the kernel applies
             bases, scalars = gu.random_case(curve, group, f"gpu:split2:{curve}:{n}:{c}", n)
-            if n == 2048:   # all pairs equal: both halves of a bucket sum to the same point, the join is a doubling
+            if n == 2048:   # all pairs equal: the slices of a bucket sum to the same point, the join is a doubling
                 bases = bases[:A] * n
                 scalars = scalars[:32] * n
             exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
             eng.set_window_bits(c)
             eng.set_option("segment", seg)
-            got = {}
-            for on in (1, 0):
-                eng.set_option("split2", on)
-                got[on] = C.g1m_multiexpAffine(bases, scalars, 32, n)
-            assert got[1] == got[0] == gu.canon(curve, group, exp, O.zero()), (curve, n, c, seg)
+            eng.set_option("split2", 0)
+            one_lane = C.g1m_multiexpAffine(bases, scalars, 32, n)
+            assert one_lane == gu.canon(curve, group, exp, O.zero()), (curve, n, c, seg)
+            eng.set_option("split2", 1)
+            for k in (0, 2, 3, 7, 64):
+                eng.set_option("splitk", k)
+                assert C.g1m_multiexpAffine(bases, scalars, 32, n) == one_lane, (curve, n, c, seg, k)
+        with pytest.raises(Exception):
+            eng.set_option("splitk", 65)
     finally:
         eng.set_option("split2", 1)
+        eng.set_option("splitk", 0)
         eng.set_option("segment", 0)
         eng.set_window_bits(0)
 

@@ -43,7 +43,9 @@ MSM_D Affine<F> load_point(const uint8_t* __restrict__ bases, const uint8_t* __r
     return p;
 }
 // (Requesting the point of entry k+1 before the addition of entry k was measured: no gain at 2 waves/SIMD, and at 3 waves
-// the 24 extra registers spill -- the gather latency is already covered by the other waves' ~4600 VALU instructions.)
+// the 24 extra registers spill -- the gather latency is already covered by the other waves' ~4600 VALU instructions.  So was
+// touching the next point's lines with two unused dword loads, which costs two registers: 5-10 % SLOWER at every size, n = 2^20
+// to 2^26, both curves -- the accumulation at large n is not waiting for gather latency.)
 // For a lane-paired kind (UG2P) both lanes of a pair walk the same entries; each loads its own component of x and y.
 template <class F>
 MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted, uint32_t first,
@@ -55,21 +57,23 @@ MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __
         if constexpr (K::LANES == 1) {
             const Affine<F> p = load_point<F>(bases, xbeta, e & 0x7fffffffu);
             const uint32_t* w = reinterpret_cast<const uint32_t*>(&p);
-            if (words_all_zero(w, 2 * K::WORDS)) continue;   // affine infinity (build_curve_jacobian_a0.js:124-171)
-            auto x2 = K::load(w);
-            auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
-            BU<F>::madd(acc, x2, y2);
+            if (!words_all_zero(w, 2 * K::WORDS)) {   // else affine infinity (build_curve_jacobian_a0.js:124-171)
+                auto x2 = K::load(w);
+                auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
+                BU<F>::madd(acc, x2, y2);
+            }
         } else {
             using B = typename F::B;                          // base field of the packed Fp2 coordinate: x = c0 || c1, y = c0 || c1
             const uint8_t* pp = bases + (size_t)(e & 0x7fffffffu) * sizeof(Affine<F>) + pair_parity() * sizeof(B);
             const B xo = load16<B>(pp);
             const B yo = load16<B>(pp + sizeof(F));
             const uint32_t z = (words_all_zero(xo.v, B::N) && words_all_zero(yo.v, B::N)) ? 1u : 0u;
-            if (z & pair_xchg(z)) continue;                   // all four components zero
-            typename K::In x2{u_from_packed<typename K::Params>(xo.v)};
-            typename K::In yl{u_from_packed<typename K::Params>(yo.v)};
-            auto y2 = fcneg(yl, (e >> 31) != 0);
-            BU<F>::madd(acc, x2, y2);
+            if (!(z & pair_xchg(z))) {                        // else all four components zero
+                typename K::In x2{u_from_packed<typename K::Params>(xo.v)};
+                typename K::In yl{u_from_packed<typename K::Params>(yo.v)};
+                auto y2 = fcneg(yl, (e >> 31) != 0);
+                BU<F>::madd(acc, x2, y2);
+            }
         }
     }
     return acc;
@@ -130,38 +134,42 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
     }
 }
 
-// Two lanes per bucket (G1 kinds): a launch with few buckets -- the windows one rank of a sharded call owns, a small n -- would put a
-// single wave on each SIMD, where dependent multiply-adds issue at barely half rate.  Here lanes 2r and 2r+1 each add half of bucket
-// r's entries and the halves are joined with one DPP exchange and one addition: twice the waves for ~1/mean more work.
-template <class F>
-__global__ void __launch_bounds__(256) k_accumulate_split2(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
+// K lanes per bucket (G1 kinds).  A launch with few buckets -- the windows one rank of a sharded call owns, a small n -- would put one
+// or two waves on each SIMD with chains as long as the bucket population (65536 buckets of 2048 entries at n = 2^26 over 8 ranks: one
+// wave per SIMD walking 2048 additions, 20 us each).  Here bucket r is cut into K slices of ceil(cnt / K) entries; wave w adds slice
+// w mod K of the 64 buckets [64 (w / K), +64) (the lanes of one wave stay as evenly loaded as the buckets are) and leaves its sums in
+// `slices`; k_join_slices adds the K sums of every bucket.  The engine picks K so that the launch brings three waves to every SIMD.
+// One wave per workgroup, like k_accumulate: with K waves per workgroup joined through LDS the waves were placed unevenly over the
+// SIMDs (n = 2^26 / 8 ranks, K = 2: 30.5 ms against 20 ms for the same lanes as single-wave workgroups).
+// `seg` bounds the entries of ONE lane; what a bucket holds beyond K * seg is queued for the tail kernels in segments of that length.
+template <class F, int VARIANT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate_slices(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
-                                                            const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
-                                                            TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+                                                            const uint32_t* __restrict__ order, uint32_t nb, uint32_t K, uint8_t* __restrict__ slices, uint32_t seg) {
     static_assert(UKind<F>::type::LANES == 1, "one-lane kinds only");
-    const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t r = gt >> 1, s = gt & 1u;
-    if (r >= nb) return;   // both lanes of a pair leave together
-    const uint32_t b = order[r], cnt = count[b], off = offset[b];
-    const uint32_t tot = min(cnt, 2u * seg), chunk = (tot + 1u) >> 1;
-    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, off + s * chunk, s ? tot - chunk : chunk);
-    BU<F> other;
-    {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(&acc);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&other);
-#pragma unroll
-        for (int k = 0; k < (int)(sizeof(BU<F>) / 4); ++k) dst[k] = pair_xchg(src[k]);
-    }
-    acc = BU<F>::add(acc, other);
-    if (s == 0) {
-        store16(buckets + (size_t)b * sizeof(BU<F>), acc);
-        if (cnt > 2u * seg) {
-            const uint32_t done = 2u * seg, extra = (cnt - done + seg - 1u) / seg;
-            uint32_t base = atomicAdd(&ctl->nwork, extra);
-            uint32_t bi = atomicAdd(&ctl->nbig, 1u);
-            biglist[bi] = make_uint4(b, base, extra, 0u);
-            for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
-        }
+    const uint32_t s = blockIdx.x % K, r = (blockIdx.x / K) * 64u + threadIdx.x;
+    if (r >= nb) return;
+    const uint32_t b = order[r], cnt = count[b];
+    const uint32_t tot = min(cnt, K * seg), chunk = (tot + K - 1u) / K, first = min(s * chunk, tot);
+    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[b] + first, min(chunk, tot - first));
+    store16(slices + ((size_t)s * nb + r) * sizeof(BU<F>), acc);
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, uint32_t nb, uint32_t K,
+                                                     const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
+                                                     TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= nb) return;
+    BU<F> acc = load16<BU<F>>(slices + (size_t)r * sizeof(BU<F>));
+    for (uint32_t s = 1; s < K; ++s) acc = BU<F>::add_ni(acc, load16<BU<F>>(slices + ((size_t)s * nb + r) * sizeof(BU<F>)));
+    const uint32_t b = order[r], cnt = count[b];
+    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
+    if (cnt > K * seg) {
+        const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
+        uint32_t base = atomicAdd(&ctl->nwork, extra);
+        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
+        biglist[bi] = make_uint4(b, base, extra, 0u);
+        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
     }
 }
 
@@ -181,6 +189,10 @@ __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restri
     }
 }
 
+// A bucket's queued segments are summed by a whole workgroup (LDS tree) when they are many -- adversarial inputs: one bucket, tens of
+// thousands of segments -- and by one lane when they are few: the 2^14 twice-as-dense buckets of a narrow top window, cut into a handful
+// of segments each by a sliced launch, would otherwise take one workgroup iteration apiece (16384 iterations over 64 workgroups).
+constexpr uint32_t TAIL_LANE_SEGS = 24;   // up to this many segments: k_combine_tail_lanes
 template <class F>
 __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict__ ctl, const uint4* __restrict__ biglist,
                                                        const uint8_t* __restrict__ seg_out, uint8_t* __restrict__ buckets) {
@@ -191,6 +203,7 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
     const uint32_t nbig = ctl->nbig;
     for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         uint4 d = biglist[bi];   // bucket, first segment, number of segments
+        if (d.z <= TAIL_LANE_SEGS) continue;   // (uniform over the workgroup)
         BU<F> loc = BU<F>::inf();
         for (uint32_t j = lt; j < d.z; j += nlt)
             loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
@@ -209,6 +222,19 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
             store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), BU<F>::add_ni(cur, sh[threadIdx.x]));
         }
         __syncthreads();
+    }
+}
+template <class F>
+__global__ void __launch_bounds__(64) k_combine_tail_lanes(const TailCtl* __restrict__ ctl, const uint4* __restrict__ biglist,
+                                                            const uint8_t* __restrict__ seg_out, uint8_t* __restrict__ buckets) {
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    const uint32_t nbig = ctl->nbig, gt = blockIdx.x * blockDim.x + threadIdx.x, sub = gt % T;
+    for (uint32_t bi = gt / T; bi < nbig; bi += gridDim.x * blockDim.x / T) {   // (both lanes of a pair take the same trips)
+        uint4 d = biglist[bi];
+        if (d.z > TAIL_LANE_SEGS) continue;
+        BU<F> acc = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
+        for (uint32_t j = 0; j < d.z; ++j) acc = BU<F>::add_ni(acc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
+        store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), acc);
     }
 }
 
@@ -374,11 +400,20 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbet
     k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK), MSM_ACC_BLOCK, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
                                                                                 (uint2*)work, (uint4*)biglist);
 }
+template <class F, int VARIANT>
+void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
+                              const uint32_t* count, const uint32_t* order, uint32_t nb, uint8_t* slices, uint32_t seg) {
+#if defined(MSM_U_CHAINED_MADS)
+    static_assert(VARIANT == 1, "this translation unit builds the chained variant");
+#else
+    static_assert(VARIANT == 0, "this translation unit builds the two-chain variant");
+#endif
+    k_accumulate_slices<F, VARIANT><<<((nb + 63u) / 64u) * k, 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, k, slices, seg);
+}
 template <class F>
-void launch_accumulate_split2(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                              const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
-    k_accumulate_split2<F><<<(uint32_t)(((uint64_t)nb * 2 + 63) / 64), 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
-                                                                               (uint2*)work, (uint4*)biglist);
+void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const uint32_t* order, uint32_t nb, const uint8_t* slices, uint8_t* buckets,
+                        uint32_t seg, void* ctl, void* work, void* biglist) {
+    k_join_slices<F><<<(nb + 63u) / 64u, 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work, (uint4*)biglist);
 }
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
@@ -387,6 +422,7 @@ void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t*
     k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
     constexpr uint32_t T = UKind<F>::type::LANES;   // tail_block and rblock count LOGICAL lanes (points); a point takes T threads
     k_combine_tail<F><<<64, tail_block * T, (size_t)tail_block * T * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
+    k_combine_tail_lanes<F><<<512, 64, 0, st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
@@ -411,9 +447,11 @@ uint32_t lanes_per_point() {
 #define MSM_INSTANTIATE_ACCUMULATE(F, VARIANT)                                                                                               \
     template void launch_accumulate<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
                                        uint32_t, uint8_t*, uint32_t, void*, void*, void*);
-#define MSM_INSTANTIATE_SPLIT2(F)                                                                                                            \
-    template void launch_accumulate_split2<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                              uint32_t, uint8_t*, uint32_t, void*, void*, void*);
+#define MSM_INSTANTIATE_SLICES(F, VARIANT)                                                                                                   \
+    template void launch_accumulate_slices<F, VARIANT>(hipStream_t, uint32_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
+                                                       const uint32_t*, uint32_t, uint8_t*, uint32_t);
+#define MSM_INSTANTIATE_JOIN(F)                                                                                                              \
+    template void launch_join_slices<F>(hipStream_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_TAIL(F)                                                                                                              \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
                                             uint32_t, void*, void*, void*, uint8_t*, uint32_t);

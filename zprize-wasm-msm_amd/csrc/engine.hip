@@ -27,9 +27,12 @@ namespace msm {
 template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+template <class F, int VARIANT>
+void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
+                              const uint32_t* count, const uint32_t* order, uint32_t nb, uint8_t* slices, uint32_t seg);
 template <class F>
-void launch_accumulate_split2(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                              const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const uint32_t* order, uint32_t nb, const uint8_t* slices, uint8_t* buckets,
+                        uint32_t seg, void* ctl, void* work, void* biglist);
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
@@ -395,9 +398,34 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     }
     // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation).
-    // A SMALL accumulation (fewer than two waves per SIMD: few owned windows of a sharded call, small n) cannot fill the
-    // chip by itself, so it goes to the slot's own stream instead and may overlap the accumulations of the other calls in flight.
-    const bool small_acc = NB < 2u * 1024u * 64u && !split_mode;
+    // A SMALL accumulation (buckets for fewer than five waves per SIMD: few owned windows of a sharded call, small n) goes to the
+    // slot's own stream instead and may overlap the accumulations of the other calls in flight: measured better or equal whenever
+    // the launch is short of ~1.5 rounds, also when its buckets are cut into slices (n = 2^20 over 4 ranks: 1.12 vs 1.25 ms per
+    // call; n = 2^26 over 8 ranks: 25.2 vs 26.7).
+    const uint32_t mean = (nv + g.half - 1) / g.half;
+    // lanes per bucket (k_accumulate_slices; 1 = the plain kernel).  Two reasons to cut buckets into slices, both measured on the
+    // windows one rank of a sharded call owns (profiles/r02_slices_sweep.txt):
+    //  (a) too few buckets to occupy the chip: bring the launch to ~320k lanes (five waves per SIMD, i.e. 1.67 rounds of the three
+    //      that fit) -- n = 2^20 over 4 ranks, 163840 buckets of 32: 1.12 -> 1.01 ms per call with two lanes per bucket;
+    //  (b) long buckets: chains of ~128 entries instead of thousands, as long as the launch stays below 2^21 lanes -- n = 2^26 over
+    //      8 ranks, 65536 buckets of 2048: 44.7 ms with one lane per bucket, 26.4 with 3 (one round of three waves per SIMD),
+    //      25.0 with 8, 24.2 with 16.
+    // Every lane keeps at least 8 entries (the join costs one full addition per slice).  Option "splitk" forces a value,
+    // "split2" = 0 keeps every bucket on one lane.
+    auto lanes_per_bucket = [&](uint32_t nbk) -> uint32_t {
+        if constexpr (!KernelField<F>::chained_variant) return 1u;
+        if (ctx->no_split2 || nbk == 0) return 1u;
+        uint32_t k = ctx->splitk;
+        if (!k) {
+            const uint32_t k_occupancy = ctx->splitk_lanes / nbk;
+            const uint32_t k_chain = std::min<uint32_t>(mean / 128u, (1u << 21) / nbk);
+            k = std::min<uint32_t>(std::max(k_occupancy, k_chain), MAX_SLICES);
+        }
+        while (k > 1 && mean / k < 8) --k;
+        return std::max(k, 1u);
+    };
+    const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
+    const bool small_acc = ctx->acc_stream ? ctx->acc_stream == 1 : (NB < 5u * 1024u * 64u && !split_mode);
     st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
     HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
     HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
@@ -406,7 +434,6 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // on one lane, ~0.6 ms at seg = 32, which a 2x-the-mean rule paid at mean = 16).  Longer buckets -- adversarial scalars, or
     // the few buckets of a narrow top window when the scalar width is not a multiple of c -- are cut into segments, which
     // bounds the longest dependent chain of additions.
-    const uint32_t mean = (nv + g.half - 1) / g.half;
     // A top window that the scalar bits only partly fill (c = 20 over 256 bits: 16 bits of 20) uses 2^tb of its buckets, each
     // 2^(c-1-tb) times denser than the rest.  When those are many (>= 4096: 64 waves) they run as ordinary lanes with longer
     // chains -- started first, since buckets are ordered by falling population -- rather than as segments for the tail kernels
@@ -425,41 +452,44 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nv) / 245760u, 1u << 20);
         seg = std::max(seg, std::min(seg_hi, cap));
     }
-    const size_t max_segs = (size_t)g.Wl * nv / seg + 1;
+    const uint32_t seg_min = (seg + std::max(k_first, k_second) - 1) / std::max(k_first, k_second);
+    const size_t max_segs = (size_t)g.Wl * nv / seg_min + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
     if (int rc = ensure(ctx, sl->d_segout, max_segs * BSZ)) return rc;
-    HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+    if (k_first > 1 || k_second > 1)
+        if (int rc = ensure(ctx, sl->d_slices, std::max((size_t)split * k_first, (size_t)(NB - split) * k_second) * BSZ)) return rc;
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
     uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
-    // G1 has two builds of the accumulation kernel (bucket_kernels.hpp): the chained one when the launch puts at least two waves
+    // G1 has two builds of the accumulation kernels (bucket_kernels.hpp): the chained one when the launch puts at least two waves
     // on every SIMD, the two-chain one otherwise
-    auto accumulate = [&](const uint32_t* ord, uint32_t nbk) {
-        if constexpr (KernelField<F>::chained_variant) {
-            // few buckets with enough entries each (the windows of one rank of a sharded call): two lanes per bucket
-            if (!ctx->no_split2 && nbk < ctx->split2_nb && mean >= 16) {
-                launch_accumulate_split2<FK>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
-                return;
-            }
-            if ((uint64_t)nbk >= 2u * 1024u * 64u) {
-                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
-                return;
-            }
-        }
-        launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
-    };
-    accumulate(order, split);
-    launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
-                               (uint8_t*)sl->d_segout.p, tail_block);
-    HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
-    if (split < NB) {
+    auto accumulate = [&](const uint32_t* ord, uint32_t nbk, uint32_t k) -> int {
         HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
-        accumulate(order + split, NB - split);
-        launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+        const uint32_t seg_lane = (seg + k - 1) / k;
+        if constexpr (KernelField<F>::chained_variant) {
+            const bool chained = ctx->acc_variant ? ctx->acc_variant == 2 : (uint64_t)nbk * k >= 2u * 1024u * 64u;
+            if (k > 1) {
+                uint8_t* slices = (uint8_t*)sl->d_slices.p;
+                if (chained) launch_accumulate_slices<FK, 1>(st, k, d_bases, d_xbeta, sorted, offset, count, ord, nbk, slices, seg_lane);
+                else launch_accumulate_slices<FK, 0>(st, k, d_bases, d_xbeta, sorted, offset, count, ord, nbk, slices, seg_lane);
+                launch_join_slices<FK>(st, k, count, ord, nbk, slices, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+            } else if (chained)
+                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+            else
+                launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+        } else {
+            launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+        }
+        launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                                    (uint8_t*)sl->d_segout.p, tail_block);
-    }
+        return 0;
+    };
+    if (int rc = accumulate(order, split, k_first)) return rc;
+    HIPCHK(ctx, hipEventRecord(sl->ev[8], st));   // first group accumulated
+    if (split < NB)
+        if (int rc = accumulate(order + split, NB - split, k_second)) return rc;
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
     // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
     hipStream_t sb = sl->stream_b;
@@ -985,7 +1015,14 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "sort_big")) { ctx->sort_big = value > 2 ? 0 : (int)value; return 0; }
     if (!strcmp(name, "glv")) { ctx->glv_mode = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split2")) { ctx->no_split2 = value == 0; return 0; }
-    if (!strcmp(name, "split2_nb")) { ctx->split2_nb = value; return 0; }
+    if (!strcmp(name, "splitk")) {
+        if (value > MAX_SLICES) return MSM_AMD_EINVAL;
+        ctx->splitk = value;
+        return 0;
+    }
+    if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A
+    if (!strcmp(name, "acc_variant")) { ctx->acc_variant = value; return 0; }   // experiments: 1 = two-chain build, 2 = chained build, 0 = by launch size
+    if (!strcmp(name, "splitk_lanes")) { ctx->splitk_lanes = value ? value : 5u * 1024u * 64u; return 0; }
     if (!strcmp(name, "slice")) {
         if (value < 1 || value > (1u << 27)) { msm_set_err(ctx, "slice must be in [1, 2^27]"); return MSM_AMD_EINVAL; }
         ctx->max_slice = value;

@@ -33,7 +33,7 @@ using namespace msm;
 // two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
 // the sort + accumulation of the next call (throughput-bound, stream A).
 struct Slot {
-    DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout;
+    DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout, d_slices;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
     const void* binhist_zero = nullptr;   // == d_binhist.p while that buffer is known to be all zero (sort: k_bin_scan leaves it so)
@@ -53,9 +53,11 @@ struct Slot {
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
-    DevBuf* bufs[23] = {&d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+    DevBuf* bufs[24] = {&d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
+
+constexpr uint32_t MAX_SLICES = 64;   // lanes per bucket of a sliced accumulation
 
 struct msm_nccl_id {   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
     char internal[128];
@@ -91,8 +93,10 @@ struct msm_amd_ctx {
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
-    int no_split2 = 0;      // option "split2" = 0 switches the two-lanes-per-bucket accumulation of small launches off
-    uint32_t split2_nb = 2u * 1024u * 64u;   // option "split2_nb": launches with fewer buckets than this use it (default: two waves per SIMD)
+    int no_split2 = 0;      // option "split2" = 0: one lane per bucket always (switches k_accumulate_slices off)
+    uint32_t acc_variant = 0, acc_stream = 0;
+    uint32_t splitk = 0;    // option "splitk": lanes per bucket of the G1 accumulation, 0 = chosen per launch, 1..MAX_SLICES forced
+    uint32_t splitk_lanes = 5u * 1024u * 64u;   // option "splitk_lanes": the lane count a launch with few buckets is brought to (five waves for each of 1024 SIMDs)
     uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
