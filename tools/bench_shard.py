@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--depth", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--bits", type=int, default=255, help="significant bits of the random scalars (256: half of them carry into a 17th 16-bit window, one bucket holding n/2 entries)")
+    ap.add_argument("--same", action="store_true", help="adversarial: every scalar equal (one bucket per window holds all n entries)")
     ap.add_argument("--bits254", action="store_true", help="254-bit scalars: the top 16-bit window then holds 14 bits, its buckets are twice as dense")
     ap.add_argument("--dummy-streams", type=int, default=0,
                     help="create this many idle HIP streams before the engine (shifts the stream-to-hardware-queue mapping: DESIGN.md section 7)")
@@ -88,7 +90,12 @@ def main():
     pts = C.gen_points(1, 77, n)
     rng = np.random.default_rng(5)
     sc = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    sc[:, 31] &= 0x7F if not a.bits254 else 0x3F      # 255 significant bits (BLS12-381's order); --bits254: one bit fewer (BN254's)
+    bits = 254 if a.bits254 else a.bits               # 255 significant bits (BLS12-381's order); --bits254: one bit fewer (BN254's)
+    if bits < 256:
+        sc[:, bits // 8 + 1:] = 0
+        sc[:, bits // 8] &= (1 << (bits % 8)) - 1
+    if a.same:
+        sc[:] = sc[0]
     ds = eng.alloc(n * 32).upload(sc.tobytes())
     for _ in range(3):
         C.multiexp_shard(1, pts, ds, 32, n, a.rank, a.world)

@@ -79,6 +79,53 @@ MSM_D BU<F> accumulate_span(const uint8_t* __restrict__ bases, const uint8_t* __
     return acc;
 }
 
+// The same for a whole single-wave workgroup of one-lane kinds, with the entry lists staged through LDS.  Lane l walks its own list
+// sorted[first_l ..): read lane by lane that is one 4-byte load per addition from 64 different lines, each line wanted again 31
+// additions later -- by then evicted from the 32 KB L1 (768 such streams per CU) and, at large n, from L2 as well: the counters show
+// ~2 L2 requests per addition and twice the algorithmic bytes from HBM.  Here the wave fetches 32 entries of every lane's list at a
+// time, two lists per load instruction (one 128-byte line each), into a [64][33] tile; every lane then takes its entries from LDS
+// (stride 33: conflict-free), and the point gather no longer waits behind a dependent load of the entry.
+constexpr uint32_t STAGE_T = 32, STAGE_STRIDE = 33, STAGE_WORDS = 64 * STAGE_STRIDE + 128;   // the tile, then first[64] and len[64]
+template <class F>
+MSM_D BU<F> accumulate_span_staged(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted, uint32_t first,
+                                   uint32_t len, uint32_t* __restrict__ tile) {
+    using K = typename UKind<F>::type;
+    static_assert(K::LANES == 1, "one-lane kinds only");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* meta = tile + 64 * STAGE_STRIDE;   // the lists' starts and lengths live in LDS, not in registers, across the additions
+    meta[lane] = first;
+    meta[64 + lane] = len;
+    uint32_t longest = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) longest = max(longest, (uint32_t)__shfl_xor((int)longest, d, 64));
+    longest = __builtin_amdgcn_readfirstlane(longest);
+    BU<F> acc = BU<F>::inf();
+    // one loop with a wave-uniform trip count (a wave runs until its longest lane is done anyway): counter and refill test are scalar
+    for (uint32_t k = 0; k < longest; ++k) {
+        if ((k & (STAGE_T - 1u)) == 0) {
+            __syncthreads();
+            const uint32_t half = lane >> 5, sub = lane & 31u, j = k + sub;
+#pragma unroll 8
+            for (uint32_t i = 0; i < 32; ++i) {
+                const uint32_t src = 2 * i + half;
+                if (j < meta[64 + src]) tile[src * STAGE_STRIDE + sub] = sorted[meta[src] + j];
+            }
+            __syncthreads();
+        }
+        if (k < meta[64 + lane]) {
+            const uint32_t e = tile[lane * STAGE_STRIDE + (k & (STAGE_T - 1u))];
+            const Affine<F> pt = load_point<F>(bases, xbeta, e & 0x7fffffffu);
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(&pt);
+            if (!words_all_zero(w, 2 * K::WORDS)) {
+                auto x2 = K::load(w);
+                auto y2 = fcneg(K::load(w + K::WORDS), (e >> 31) != 0);
+                BU<F>::madd(acc, x2, y2);
+            }
+        }
+    }
+    return acc;
+}
+
 // Full additions inside the reduction: expanded inline for the G1 fields (the kernel runs one wave per
 // SIMD and is latency-bound; calls would spill the three live points around every addition), out of
 // line for Fp2 where the inlined body would be ~3x larger.
@@ -104,6 +151,9 @@ struct ReduceInline {
 #ifndef MSM_ACC_WAVES
 #define MSM_ACC_WAVES 3
 #endif
+#ifndef MSM_ACC_STAGED
+#define MSM_ACC_STAGED 1   // entry lists of the G1 accumulation staged through LDS (accumulate_span_staged)
+#endif
 template <class F>
 struct AccWaves {
     static constexpr int value = InlineAdds<F>::value ? MSM_ACC_WAVES : (UKind<F>::type::LANES == 2 ? 2 : 1);
@@ -119,11 +169,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
     constexpr uint32_t T = UKind<F>::type::LANES;   // lanes per bucket (2: Fp2 components on a lane pair)
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = gt / T, sub = gt % T;
-    if (r >= nb) return;
-    uint32_t b = order[r];
-    uint32_t cnt = count[b];
-    uint32_t off = offset[b];
-    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, seg));
+    uint32_t b = 0, cnt = 0, off = 0;
+    BU<F> acc;
+#if MSM_ACC_STAGED
+    if constexpr (T == 1) {   // (launched as single-wave workgroups: MSM_ACC_BLOCK)
+        __shared__ uint32_t tile[STAGE_WORDS];
+        if (r < nb) {
+            b = order[r];
+            cnt = count[b];
+            off = offset[b];
+        }
+        acc = accumulate_span_staged<F>(bases, xbeta, sorted, off, min(cnt, seg), tile);
+        if (r >= nb) return;
+    } else
+#endif
+    {
+        if (r >= nb) return;
+        b = order[r];
+        cnt = count[b];
+        off = offset[b];
+        acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, seg));
+    }
     store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
     if (cnt > seg && sub == 0) {
         uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
@@ -148,10 +214,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
                                                             const uint32_t* __restrict__ order, uint32_t nb, uint32_t K, uint8_t* __restrict__ slices, uint32_t seg) {
     static_assert(UKind<F>::type::LANES == 1, "one-lane kinds only");
     const uint32_t s = blockIdx.x % K, r = (blockIdx.x / K) * 64u + threadIdx.x;
+#if MSM_ACC_STAGED
+    __shared__ uint32_t tile[STAGE_WORDS];
+    uint32_t from = 0, len = 0;
+    if (r < nb) {
+        const uint32_t b = order[r], cnt = count[b];
+        const uint32_t tot = min(cnt, K * seg), chunk = (tot + K - 1u) / K, first = min(s * chunk, tot);
+        from = offset[b] + first;
+        len = min(chunk, tot - first);
+    }
+    BU<F> acc = accumulate_span_staged<F>(bases, xbeta, sorted, from, len, tile);
+    if (r >= nb) return;
+#else
     if (r >= nb) return;
     const uint32_t b = order[r], cnt = count[b];
     const uint32_t tot = min(cnt, K * seg), chunk = (tot + K - 1u) / K, first = min(s * chunk, tot);
     BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[b] + first, min(chunk, tot - first));
+#endif
     store16(slices + ((size_t)s * nb + r) * sizeof(BU<F>), acc);
 }
 template <class F>
@@ -396,6 +475,9 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbet
     // CU can host four (measured: 2.29 -> 2.24 ms for the kernel at n = 2^20)
 #ifndef MSM_ACC_BLOCK
 #define MSM_ACC_BLOCK 64
+#endif
+#if MSM_ACC_STAGED
+    static_assert(MSM_ACC_BLOCK == 64, "the staged entry lists take single-wave workgroups");
 #endif
     k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK), MSM_ACC_BLOCK, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
                                                                                 (uint2*)work, (uint4*)biglist);
