@@ -183,6 +183,30 @@ def test_all_equal_scalars_take_the_long_span_paths(eng, orc):
         eng.set_option("sort_big", 0)
 
 
+@pytest.mark.parametrize("curve", ["bls12381", "bn128"])
+def test_scalar_widths_that_leave_dense_or_carry_buckets(eng, orc, curve):
+    """Scalars are plain 32-byte integers to the reference (build_multiexp.js:36-94 slices bits, nothing reduces mod r).  Widths that
+    are not the group order's make some buckets far denser than the rest: 256 bits -- half of the scalars carry out of the top 16-bit
+    window into a 17th whose single bucket then holds n/2 entries; 250 or 243 bits -- a narrow top window, few buckets, each 2^k
+    times the mean.  Those buckets are cut into segments (tail kernels: one lane per bucket for a few segments, a workgroup for many)
+    and, with a narrow forced window, the launch is sliced as well: every combination has to match the oracle."""
+    import random
+    group, n = 1, 20000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, _ = gu.random_case(curve, group, f"gpu:widths:{curve}", n)
+    rnd = random.Random(f"widths:{curve}")
+    try:
+        for bits in (256, 250, 243):
+            scalars = b"".join((rnd.getrandbits(bits) | (rnd.getrandbits(1) << (bits - 1))).to_bytes(32, "little") for _ in range(n))
+            exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+            for c in (0, 11):
+                eng.set_window_bits(c)
+                assert C.g1m_multiexpAffine(bases, scalars, 32, n) == gu.canon(curve, group, exp, O.zero()), (curve, bits, c)
+    finally:
+        eng.set_window_bits(0)
+
+
 def test_blocked_fft_building_blocks_match_the_reference(eng, orc):
     """<p>_fftJoin / _fftJoinExt / _fftJoinExtInv / _prepareLagrangeEvaluation / _fftMix / _fftFinal for p = frm (byte for byte), g1m, g2m
     (as normalised points) and frm_batchTo/FromMontgomery == the reference WASM (tests/golden/golden_fft2.json, oracle/gen_golden_fft2.js).
