@@ -101,9 +101,10 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
 def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     """The reference's g1m_multiexpAffine is integer arithmetic on curve points: exact for points outside the order-r subgroup too.
     The engine's GLV schedule (k mod r, endomorphism) is not -- so it only runs for callers that pass MSM_AMD_BASES_IN_SUBGROUP.
-    n = 4500 sits in the range (16-bit windows, n <= 2^17) where the GLV schedule is the default for flagged calls."""
+    n = 100000 sits in the range (16-bit windows: 98304 <= n <= 2^17) where the GLV schedule is the default for flagged calls; a
+    smaller n = 4500 (8-bit windows, no GLV schedule whatever the flag says) is checked as well."""
     import msm_amd
-    curve, group, n = "bls12381", 1, 4500
+    curve, group, n = "bls12381", 1, 100000
     C = eng.curve(curve)
     O = orc.Oracle(curve, group)
     with open(os.path.join(gu.GOLDEN, "golden_ingroup.json")) as f:
@@ -129,6 +130,11 @@ def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     assert C.g1m_multiexpAffine(good, gs, 32, n, in_subgroup=True) == expg
     assert eng.geometry()["windows"] == 8
     assert C.g1m_multiexpAffine(good, gs, 32, n) == expg
+    m = 4500
+    exps = O.normalize(O.multiexp_affine(bases[:96 * m], scalars[:32 * m], 32, m))
+    for flag in (False, True):                                  # the flag is the caller's word about the bases; here it changes nothing
+        assert C.g1m_multiexpAffine(bases[:96 * m], scalars[:32 * m], 32, m, in_subgroup=flag) == exps
+        assert eng.geometry()["windows"] == 33
 
 
 @pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 2)])

@@ -3,6 +3,7 @@ against (a) the committed golden vectors produced by the reference WASM, (b) the
 inputs, (c) size-independent properties at the BASELINE sizes.  Integer work: the bar is bit-exact
 equality of the normalised Jacobian bytes."""
 import os
+import sys
 
 import pytest
 
@@ -227,6 +228,8 @@ def test_randomised_configurations(eng, orc):
             eng.set_option("reduce_l", rnd.choice([0, 0, 1, 2, 16]))
             eng.set_option("split", rnd.choice([0, 1]))
             mode = rnd.choice(["full", "full", "chunk", "shard"])
+            if os.environ.get("MSM_TEST_TRACE"):
+                print("randomised", it, curve, group, n, ss, mode, file=sys.stderr, flush=True)
             if mode == "full":
                 exp = O.normalize(O.multiexp_affine(bases, scalars, ss, n))
                 got = _fn(C, group, True)(bases, scalars, ss, n)
@@ -285,11 +288,13 @@ def test_split_window_groups(eng, orc):
     bases, scalars = gu.random_case(curve, group, "gpu:split", n)
     exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
     eng.set_option("split", 1)
+    eng.set_window_bits(16)
     try:
         assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp
         assert eng.geometry()["c"] == 16
     finally:
         eng.set_option("split", 0)
+        eng.set_window_bits(0)
 
 
 @pytest.mark.parametrize("curve", ["bls12381", "bn128"])
@@ -314,7 +319,7 @@ def test_several_lanes_per_bucket(eng, orc, curve):
             one_lane = C.g1m_multiexpAffine(bases, scalars, 32, n)
             assert one_lane == gu.canon(curve, group, exp, O.zero()), (curve, n, c, seg)
             eng.set_option("split2", 1)
-            for k in (0, 2, 3, 7, 64):
+            for k in (0, 2, 3, 7, 8, 16, 64):   # 8 and up, powers of two: the tree join
                 eng.set_option("splitk", k)
                 assert C.g1m_multiexpAffine(bases, scalars, 32, n) == one_lane, (curve, n, c, seg, k)
         with pytest.raises(Exception):
@@ -462,8 +467,12 @@ def test_glv_path_matches_oracle_and_plain_path(eng, orc):
         assert C.g1m_multiexp(O.batch_to_jacobian(bases), scalars, 32, n) == expect     # Jacobian bases: converted, then the same path
         eng.set_option("glv", 0)
         assert C.g1m_multiexpAffine(bases, scalars, 32, n) == expect
+        assert eng.geometry()["windows"] == 33                      # n < 98304: 8-bit windows, 32 + the carry
+        eng.set_window_bits(16)
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == expect
         assert eng.geometry()["windows"] == 17
     finally:
+        eng.set_window_bits(0)
         eng.set_option("glv", 1)
 
 

@@ -252,6 +252,36 @@ __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__
     }
 }
 
+// The join for many slices per bucket (K a power of two, 8..64): a 256-lane workgroup takes 256 / K buckets, lane (s, r) loads slice s
+// of bucket r, and the slices are folded in log2 K rounds through LDS -- 6 dependent additions instead of 63 at K = 64 (a small
+// n in 8-bit windows: 4224 buckets of hundreds of entries, where the serial join was most of the accumulation stage).
+template <class F>
+__global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, uint32_t nb, uint32_t K,
+                                                          const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
+                                                          TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    BU<F>* sh = reinterpret_cast<BU<F>*>(smem);   // [K][B]
+    const uint32_t B = 256u / K, rb = threadIdx.x % B, s = threadIdx.x / B, r = blockIdx.x * B + rb;
+    const bool live = r < nb;
+    BU<F> acc = live ? load16<BU<F>>(slices + ((size_t)s * nb + r) * sizeof(BU<F>)) : BU<F>::inf();
+    for (uint32_t h = K >> 1; h >= 1; h >>= 1) {
+        if (s >= h && s < 2 * h) sh[s * B + rb] = acc;
+        __syncthreads();
+        if (s < h) acc = BU<F>::add_ni(acc, sh[(s + h) * B + rb]);
+        __syncthreads();
+    }
+    if (s != 0 || !live) return;
+    const uint32_t b = order[r], cnt = count[b];
+    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
+    if (cnt > K * seg) {
+        const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
+        uint32_t base = atomicAdd(&ctl->nwork, extra);
+        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
+        biglist[bi] = make_uint4(b, base, extra, 0u);
+        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
@@ -495,6 +525,12 @@ void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, 
 template <class F>
 void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const uint32_t* order, uint32_t nb, const uint8_t* slices, uint8_t* buckets,
                         uint32_t seg, void* ctl, void* work, void* biglist) {
+    if (k >= 8 && (k & (k - 1)) == 0 && k <= 256) {
+        const uint32_t B = 256u / k;
+        k_join_slices_tree<F><<<(nb + B - 1u) / B, 256, (size_t)256 * sizeof(BU<F>), st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work,
+                                                                                      (uint4*)biglist);
+        return;
+    }
     k_join_slices<F><<<(nb + 63u) / 64u, 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work, (uint4*)biglist);
 }
 template <class F>

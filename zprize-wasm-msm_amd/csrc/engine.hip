@@ -70,7 +70,7 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
 }
 
-static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards) {
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, bool sliced) {
     uint32_t c;
     if (forced) {
         c = forced;
@@ -94,8 +94,14 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
         }
     } else {
         // measured on MI355X (profiles/r01_sweep_window_bits*.log): the bucket reduction costs about the same whatever n is
-        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits
-        c = n >= 4096 ? 16 : 8;
+        // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits.
+        // Where the accumulation can cut buckets into slices (G1, unsharded) 8-bit windows stay ahead much longer: 33 x 128 buckets
+        // of hundreds of entries run as up to 64 lanes each and reduce in 0.28 ms instead of 0.7 (profiles/r02_sweep_window_bits_small_n.txt,
+        // ms per MSM, c = 8 | 16: BLS12-381 2^12 0.42 | 1.00, 2^14 0.49 | 0.97, 2^15 0.60 | 0.99, 2^16 0.83 | 1.02, 2^17 1.11 | 1.10;
+        // BN254 2^14 0.30 | 0.56, 2^16 0.48 | 0.58, 2^17 0.56 | 0.62, 2^18 0.92 | 0.68).  Widths between 9 and 15 lose to both: 256 is
+        // not a multiple of them and the few dense buckets of their narrow top window set the duration of the accumulation.
+        const uint32_t wide_from = sliced && nshards == 1 ? 98304u : 4096u;
+        c = n >= wide_from ? 16 : 8;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
@@ -133,9 +139,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // accumulation and reduction on their slot's own stream, several of them in flight, and the ~ten short sort kernels of the next
     // call must not queue behind one of those in a shared hardware queue (8-way shard of n = 2^20: 0.77 -> 0.56 ms per call with
     // both measures; calls with a full-size accumulation were 3-8 % slower on S2, hence two streams)
+    // the window size: by size and rank count -- except that option "glv" = 2 (tests, experiments) asks for the GLV schedule wherever it
+    // applies, and that schedule is built on 16-bit windows
+    auto window_bits = [&]() -> uint32_t {
+        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, KernelField<F>::chained_variant && !ctx->no_split2);
+        if constexpr (GlvField<F>::value)
+            if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
+        return c;
+    };
     bool small_est;
     {
-        const uint32_t c0 = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards), w0 = a.nbits / c0 + 1;
+        const uint32_t c0 = window_bits(), w0 = a.nbits / c0 + 1;
         small_est = (uint64_t)((w0 + a.nshards - 1) / a.nshards) << (c0 - 1) < 2u * 1024u * 64u;
     }
     if (small_est && !ctx->stream_s2) {
@@ -176,7 +190,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.scalar_size = a.scalar_size;
     g.bit_lo = a.bit_lo;
     g.nbits = a.nbits;
-    g.c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards);
+    g.c = window_bits();
     g.W = a.nbits / g.c + 1;
     g.half = 1u << (g.c - 1);
     g.shard = a.shard;
@@ -281,7 +295,13 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
         if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * (e32 ? 4 : 8))) return rc;
-        if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
+        {
+            // a buffer that grows is freed and allocated anew -- possibly at the SAME address, so "known to be zero" must not be keyed
+            // on the pointer alone: the bytes beyond the old capacity are whatever the allocator hands out
+            const size_t cap_before = sl->d_binhist.cap;
+            if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
+            if (sl->d_binhist.cap != cap_before) sl->binhist_zero = nullptr;
+        }
         if (int rc = ensure(ctx, sl->d_binstart, ((size_t)sg.nbins + 1) * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_bincur, (size_t)sg.nbins * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
@@ -425,6 +445,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             k = std::min<uint32_t>(std::max(k_occupancy, k_chain), MAX_SLICES);
         }
         while (k > 1 && mean / k < 8) --k;
+        if (k >= 8 && !ctx->splitk)   // the tree join (k_join_slices_tree) takes powers of two
+            while (k & (k - 1)) k &= k - 1;
         return std::max(k, 1u);
     };
     const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
