@@ -215,8 +215,6 @@ def main():
             torch.cuda.synchronize()
 
     result = None
-    for _ in range(args.warmup):
-        result = step()
     stage_acc = {}
 
     def collect():
@@ -244,29 +242,41 @@ def main():
         # previous call's gathered partials are collected and added on the host meanwhile
         gathering.append(xch.submit(out))
         return xch.result(gathering.pop(0)) if len(gathering) > 1 else None
+
+    def run(steps):
+        """`steps` MSMs the way the timed region runs them: every one submitted AND collected before this returns"""
+        res = None
+        if pipelined:
+            # `depth` steps in flight: the bucket reduction of step i (stream B) overlaps the sort + accumulation of step i+1 (stream A)
+            inflight = []
+            for _ in range(steps):
+                if not sharded:
+                    inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
+                else:
+                    inflight.append(C.multiexp_dist_async(g, pts, d_scalars, 32, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
+                if len(inflight) == depth:
+                    res = finish(inflight.pop(0))
+                    collect()
+            while inflight:
+                res = finish(inflight.pop(0))
+                collect()
+            while gathering:
+                res = xch.result(gathering.pop(0))
+        else:
+            for _ in range(steps):
+                res = step()
+                collect()
+        return res
+
+    # warmup: the same path as the timed region, and at least one call per slot in flight -- a slot allocates its scratch buffers at its
+    # first call (13 GB at n = 2^26), which a warmup of synchronous calls left to the timed region for every slot but the first
+    warm = run(max(args.warmup, depth if pipelined else 0))
+    result = warm if warm is not None else result
+    stage_acc.clear()
     sync()
     t0 = time.perf_counter()
-    if pipelined:
-        # two steps in flight: the bucket reduction of step i (stream B) overlaps the sort + accumulation of
-        # step i+1 (stream A); every step is waited for inside the timed region
-        inflight = []
-        for _ in range(args.steps):
-            if not sharded:
-                inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
-            else:
-                inflight.append(C.multiexp_dist_async(g, pts, d_scalars, 32, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
-            if len(inflight) == depth:
-                result = finish(inflight.pop(0))
-                collect()
-        while inflight:
-            result = finish(inflight.pop(0))
-            collect()
-        while gathering:
-            result = xch.result(gathering.pop(0))
-    else:
-        for _ in range(args.steps):
-            result = step()
-            collect()
+    res = run(args.steps)
+    result = res if res is not None else result
     sync()
     elapsed = time.perf_counter() - t0
     if sharded:
