@@ -82,7 +82,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice),
  * "split2" (0 = one lane per bucket always; default 1: G1 launches with few buckets cut their buckets into slices, one lane each), "splitk" (lanes per
  * bucket of such a launch: 0 = chosen per launch, 1..64 forced), "splitk_lanes" (the lane count that choice
- * brings a launch with few buckets to, default 327680). */
+ * brings a launch with few buckets to, default 327680), "reduce_pair" (1 = the G1 reduction with every point on a lane pair; measured
+ * no faster, off by default); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
+ * interleaved multiply-add chains, 2 one chain) and "acc_stream" (0 by launch size, 1 the slot's own stream, 2 the context's stream A). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 /* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
  * hardware queue (their kernels serialise).  HIP maps streams onto hardware queues in creation order across the whole process, and

@@ -641,7 +641,7 @@ def test_full_size_properties(eng, orc, curve, group, logn):
         acc = O.add(acc, fc(pts, ds, 32, n, 16 * w, 16))
     assert O.normalize(acc) == Rs
     # the eight window shards of the multi-GPU decomposition add up to the full result at full size (for G1 a rank's two or three
-    # windows are few enough buckets for the two-lanes-per-bucket accumulation)
+    # windows are few enough buckets for the sliced accumulation)
     parts = b"".join(C.multiexp_shard(group, pts, ds, 32, n, r, 8) for r in range(8))
     assert msm_amd.combine(curve, group, parts) == Rs
     # the GLV schedule (8 windows over 2n half-length scalars) and the plain 16-window schedule agree at full size
