@@ -297,18 +297,18 @@ def test_split_window_groups(eng, orc):
         eng.set_window_bits(0)
 
 
+@pytest.mark.parametrize("group", [1, 2])
 @pytest.mark.parametrize("curve", ["bls12381", "bn128"])
-def test_several_lanes_per_bucket(eng, orc, curve):
+def test_several_lanes_per_bucket(eng, orc, curve, group):
     """Launches with few, well-filled buckets give every bucket several lanes (k_accumulate_slices + k_join_slices): same bytes as
     with one lane, with odd and single-entry buckets (3001 entries over 2^7 buckets, 101 over 2^2), with long buckets cut into
     segments, and with equal partial sums meeting at the join of the slices (P + P)."""
-    group = 1
     C = eng.curve(curve)
     O = orc.Oracle(curve, group)
     A = C.affine_bytes(group)
     try:
         for n, c, seg in [(3001, 8, 0), (101, 3, 0), (1500, 6, 5), (2048, 4, 0)]:   # mean population >= 16: the kernel applies
-            bases, scalars = gu.random_case(curve, group, f"gpu:split2:{curve}:{n}:{c}", n)
+            bases, scalars = gu.random_case(curve, group, f"gpu:split2:{curve}:{group}:{n}:{c}", n)
             if n == 2048:   # all pairs equal: the slices of a bucket sum to the same point, the join is a doubling
                 bases = bases[:A] * n
                 scalars = scalars[:32] * n
@@ -316,12 +316,12 @@ def test_several_lanes_per_bucket(eng, orc, curve):
             eng.set_window_bits(c)
             eng.set_option("segment", seg)
             eng.set_option("split2", 0)
-            one_lane = C.g1m_multiexpAffine(bases, scalars, 32, n)
+            one_lane = _fn(C, group, True)(bases, scalars, 32, n)
             assert one_lane == gu.canon(curve, group, exp, O.zero()), (curve, n, c, seg)
             eng.set_option("split2", 1)
             for k in (0, 2, 3, 7, 8, 16, 64):   # 8 and up, powers of two: the tree join
                 eng.set_option("splitk", k)
-                assert C.g1m_multiexpAffine(bases, scalars, 32, n) == one_lane, (curve, n, c, seg, k)
+                assert _fn(C, group, True)(bases, scalars, 32, n) == one_lane, (curve, group, n, c, seg, k)
         with pytest.raises(Exception):
             eng.set_option("splitk", 65)
     finally:

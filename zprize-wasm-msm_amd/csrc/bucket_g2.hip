@@ -8,4 +8,6 @@ using F2a_ = Fp2<Bls12381Fp>;
 using F2b_ = Fp2<Bn254Fp>;
 MSM_INSTANTIATE_TAIL(F2a_)   // the accumulation kernels: bucket_g2_acc.hip; the reduction: bucket_g2_reduce.hip
 MSM_INSTANTIATE_TAIL(F2b_)
+MSM_INSTANTIATE_JOIN(F2a_)   // the slices of a bucket joined (out-of-line additions, like the tail kernels)
+MSM_INSTANTIATE_JOIN(F2b_)
 }  // namespace msm

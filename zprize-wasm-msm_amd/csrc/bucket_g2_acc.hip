@@ -6,4 +6,6 @@ using F2a_ = Fp2<Bls12381Fp>;
 using F2b_ = Fp2<Bn254Fp>;
 MSM_INSTANTIATE_ACCUMULATE(F2a_, 0)
 MSM_INSTANTIATE_ACCUMULATE(F2b_, 0)
+MSM_INSTANTIATE_SLICES(F2a_, 0)   // buckets cut into slices for launches with few buckets (small n in 8-bit windows, sharded ranks)
+MSM_INSTANTIATE_SLICES(F2b_, 0)
 }  // namespace msm

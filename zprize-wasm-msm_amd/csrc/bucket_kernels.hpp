@@ -212,10 +212,8 @@ template <class F, int VARIANT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate_slices(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                             const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
                                                             const uint32_t* __restrict__ order, uint32_t nb, uint32_t K, uint8_t* __restrict__ slices, uint32_t seg) {
-    static_assert(UKind<F>::type::LANES == 1, "one-lane kinds only");
-    const uint32_t s = blockIdx.x % K, r = (blockIdx.x / K) * 64u + threadIdx.x;
-#if MSM_ACC_STAGED
-    __shared__ uint32_t tile[STAGE_WORDS];
+    constexpr uint32_t T = UKind<F>::type::LANES, PER_WAVE = 64u / T;   // a lane-paired kind (G2) puts 32 buckets on a wave
+    const uint32_t s = blockIdx.x % K, r = (blockIdx.x / K) * PER_WAVE + threadIdx.x / T, sub = threadIdx.x % T;
     uint32_t from = 0, len = 0;
     if (r < nb) {
         const uint32_t b = order[r], cnt = count[b];
@@ -223,27 +221,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
         from = offset[b] + first;
         len = min(chunk, tot - first);
     }
-    BU<F> acc = accumulate_span_staged<F>(bases, xbeta, sorted, from, len, tile);
-    if (r >= nb) return;
-#else
-    if (r >= nb) return;
-    const uint32_t b = order[r], cnt = count[b];
-    const uint32_t tot = min(cnt, K * seg), chunk = (tot + K - 1u) / K, first = min(s * chunk, tot);
-    BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[b] + first, min(chunk, tot - first));
+    BU<F> acc;
+#if MSM_ACC_STAGED
+    if constexpr (T == 1) {
+        __shared__ uint32_t tile[STAGE_WORDS];
+        acc = accumulate_span_staged<F>(bases, xbeta, sorted, from, len, tile);
+    } else
 #endif
-    store16(slices + ((size_t)s * nb + r) * sizeof(BU<F>), acc);
+    {
+        acc = accumulate_span<F>(bases, xbeta, sorted, from, len);   // (both lanes of a pair hold the same from / len)
+    }
+    if (r >= nb) return;
+    store16(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>), acc);
 }
 template <class F>
 __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, uint32_t nb, uint32_t K,
                                                      const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
                                                      TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
-    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= nb) return;
-    BU<F> acc = load16<BU<F>>(slices + (size_t)r * sizeof(BU<F>));
-    for (uint32_t s = 1; s < K; ++s) acc = BU<F>::add_ni(acc, load16<BU<F>>(slices + ((size_t)s * nb + r) * sizeof(BU<F>)));
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    const uint32_t gt = blockIdx.x * 64u + threadIdx.x, r = gt / T, sub = gt % T;
+    if (r >= nb) return;   // (both lanes of a pair leave together)
+    BU<F> acc = load16<BU<F>>(slices + ((size_t)r * T + sub) * sizeof(BU<F>));
+    for (uint32_t s = 1; s < K; ++s) acc = BU<F>::add_ni(acc, load16<BU<F>>(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>)));
     const uint32_t b = order[r], cnt = count[b];
-    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
-    if (cnt > K * seg) {
+    store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
+    if (cnt > K * seg && sub == 0) {
         const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
         uint32_t base = atomicAdd(&ctl->nwork, extra);
         uint32_t bi = atomicAdd(&ctl->nbig, 1u);
@@ -260,20 +262,21 @@ __global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __rest
                                                           const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
                                                           TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    BU<F>* sh = reinterpret_cast<BU<F>*>(smem);   // [K][B]
-    const uint32_t B = 256u / K, rb = threadIdx.x % B, s = threadIdx.x / B, r = blockIdx.x * B + rb;
+    BU<F>* sh = reinterpret_cast<BU<F>*>(smem);   // [K][B][T]
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    const uint32_t B = 256u / (K * T), sub = threadIdx.x % T, rb = (threadIdx.x / T) % B, s = threadIdx.x / (T * B), r = blockIdx.x * B + rb;
     const bool live = r < nb;
-    BU<F> acc = live ? load16<BU<F>>(slices + ((size_t)s * nb + r) * sizeof(BU<F>)) : BU<F>::inf();
+    BU<F> acc = live ? load16<BU<F>>(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>)) : BU<F>::inf();
     for (uint32_t h = K >> 1; h >= 1; h >>= 1) {
-        if (s >= h && s < 2 * h) sh[s * B + rb] = acc;
+        if (s >= h && s < 2 * h) sh[(s * B + rb) * T + sub] = acc;
         __syncthreads();
-        if (s < h) acc = BU<F>::add_ni(acc, sh[(s + h) * B + rb]);
+        if (s < h) acc = BU<F>::add_ni(acc, sh[((s + h) * B + rb) * T + sub]);   // (s is the same for both lanes of a pair)
         __syncthreads();
     }
     if (s != 0 || !live) return;
     const uint32_t b = order[r], cnt = count[b];
-    store16(buckets + (size_t)b * sizeof(BU<F>), acc);
-    if (cnt > K * seg) {
+    store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
+    if (cnt > K * seg && sub == 0) {
         const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
         uint32_t base = atomicAdd(&ctl->nwork, extra);
         uint32_t bi = atomicAdd(&ctl->nbig, 1u);
@@ -520,18 +523,20 @@ void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, 
 #else
     static_assert(VARIANT == 0, "this translation unit builds the two-chain variant");
 #endif
-    k_accumulate_slices<F, VARIANT><<<((nb + 63u) / 64u) * k, 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, k, slices, seg);
+    constexpr uint32_t PER_WAVE = 64u / UKind<F>::type::LANES;
+    k_accumulate_slices<F, VARIANT><<<((nb + PER_WAVE - 1u) / PER_WAVE) * k, 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, k, slices, seg);
 }
 template <class F>
 void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const uint32_t* order, uint32_t nb, const uint8_t* slices, uint8_t* buckets,
                         uint32_t seg, void* ctl, void* work, void* biglist) {
-    if (k >= 8 && (k & (k - 1)) == 0 && k <= 256) {
-        const uint32_t B = 256u / k;
+    constexpr uint32_t T = UKind<F>::type::LANES;
+    if (k >= 8 && (k & (k - 1)) == 0 && k * T <= 256) {
+        const uint32_t B = 256u / (k * T);
         k_join_slices_tree<F><<<(nb + B - 1u) / B, 256, (size_t)256 * sizeof(BU<F>), st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work,
                                                                                       (uint4*)biglist);
         return;
     }
-    k_join_slices<F><<<(nb + 63u) / 64u, 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work, (uint4*)biglist);
+    k_join_slices<F><<<(uint32_t)(((uint64_t)nb * T + 63u) / 64u), 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work, (uint4*)biglist);
 }
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,

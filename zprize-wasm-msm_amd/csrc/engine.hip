@@ -70,7 +70,7 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
 }
 
-static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, bool sliced) {
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below) {
     uint32_t c;
     if (forced) {
         c = forced;
@@ -95,12 +95,14 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
     } else {
         // measured on MI355X (profiles/r01_sweep_window_bits*.log): the bucket reduction costs about the same whatever n is
         // (latency-bound), so 2^15 buckets per window win as soon as n reaches a few thousand; below that, 8 bits.
-        // Where the accumulation can cut buckets into slices (G1, unsharded) 8-bit windows stay ahead much longer: 33 x 128 buckets
+        // Where the accumulation cuts buckets into slices (unsharded calls) 8-bit windows stay ahead much longer: 33 x 128 buckets
         // of hundreds of entries run as up to 64 lanes each and reduce in 0.28 ms instead of 0.7 (profiles/r02_sweep_window_bits_small_n.txt,
-        // ms per MSM, c = 8 | 16: BLS12-381 2^12 0.42 | 1.00, 2^14 0.49 | 0.97, 2^15 0.60 | 0.99, 2^16 0.83 | 1.02, 2^17 1.11 | 1.10;
-        // BN254 2^14 0.30 | 0.56, 2^16 0.48 | 0.58, 2^17 0.56 | 0.62, 2^18 0.92 | 0.68).  Widths between 9 and 15 lose to both: 256 is
-        // not a multiple of them and the few dense buckets of their narrow top window set the duration of the accumulation.
-        const uint32_t wide_from = sliced && nshards == 1 ? 98304u : 4096u;
+        // ms per MSM, c = 8 | 16: BLS12-381 G1 2^12 0.42 | 1.00, 2^14 0.49 | 0.97, 2^15 0.60 | 0.99, 2^16 0.83 | 1.02, 2^17 1.11 | 1.10;
+        // BN254 G1 2^14 0.30 | 0.56, 2^16 0.48 | 0.58, 2^17 0.56 | 0.62, 2^18 0.92 | 0.68; BLS12-381 G2 2^12 0.65 | 1.58, 2^14 0.90 | 1.57,
+        // 2^16 1.73 | 1.75, 2^17 2.74 | 2.15; BN254 G2 2^14 0.48 | 0.89, 2^16 0.77 | 0.93, 2^17 1.31 | 1.06): narrow_below = 98304 for
+        // G1, 65537 for G2.  Widths between 9 and 15 lose to both: 256 is not a multiple of them and the few dense buckets of their
+        // narrow top window set the duration of the accumulation.
+        const uint32_t wide_from = nshards == 1 ? narrow_below : 4096u;
         c = n >= wide_from ? 16 : 8;
     }
     if (c > nbits) c = nbits;
@@ -142,7 +144,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // the window size: by size and rank count -- except that option "glv" = 2 (tests, experiments) asks for the GLV schedule wherever it
     // applies, and that schedule is built on 16-bit windows
     auto window_bits = [&]() -> uint32_t {
-        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, KernelField<F>::chained_variant && !ctx->no_split2);
+        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (KernelField<F>::chained_variant ? 98304u : 65537u));
         if constexpr (GlvField<F>::value)
             if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
         return c;
@@ -433,15 +435,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // Every lane keeps at least 8 entries (the join costs one full addition per slice).  Option "splitk" forces a value,
     // "split2" = 0 keeps every bucket on one lane.
     auto lanes_per_bucket = [&](uint32_t nbk) -> uint32_t {
-        if constexpr (!KernelField<F>::chained_variant) return 1u;
         if (ctx->no_split2 || nbk == 0) return 1u;
+        // G2 (a point on a lane pair, two waves per SIMD): a third of the buckets G1 needs to fill the chip
+        const uint32_t lanes_goal = KernelField<F>::chained_variant ? ctx->splitk_lanes : ctx->splitk_lanes / 3u;
+        const uint32_t lanes_max = KernelField<F>::chained_variant ? (1u << 21) : (1u << 21) / 3u;
         uint32_t k = ctx->splitk;
         if (!k) {
             // launches that occupy the chip anyway gain nothing (bn128 n = 2^24, 524288 buckets of 512: 21.9 ms/step with one lane per
             // bucket, 22.7 with 4; bls12381 n = 2^24 c = 19: 40.2 vs 44.3)
-            if (nbk >= ctx->splitk_lanes) return 1u;
-            const uint32_t k_occupancy = ctx->splitk_lanes / nbk;
-            const uint32_t k_chain = std::min<uint32_t>(mean / 128u, (1u << 21) / nbk);
+            if (nbk >= lanes_goal) return 1u;
+            const uint32_t k_occupancy = lanes_goal / nbk;
+            const uint32_t k_chain = std::min<uint32_t>(mean / 128u, lanes_max / nbk);
             k = std::min<uint32_t>(std::max(k_occupancy, k_chain), MAX_SLICES);
         }
         while (k > 1 && mean / k < 8) --k;
@@ -504,6 +508,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
                 launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
             else
                 launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+        } else if (k > 1) {
+            uint8_t* slices = (uint8_t*)sl->d_slices.p;
+            launch_accumulate_slices<FK, 0>(st, k, d_bases, d_xbeta, sorted, offset, count, ord, nbk, slices, seg_lane);
+            launch_join_slices<FK>(st, k, count, ord, nbk, slices, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         } else {
             launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         }
