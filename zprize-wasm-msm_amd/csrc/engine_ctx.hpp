@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <atomic>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -101,6 +102,7 @@ struct msm_amd_ctx {
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int reduce_pair = 0;    // option "reduce_pair" = 1: G1 bucket reduction with every point on a lane pair (measured: no gain)
+    std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
     float timings[8] = {};
     uint32_t geometry[6] = {};
