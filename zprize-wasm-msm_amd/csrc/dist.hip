@@ -87,13 +87,13 @@ int msm_amd_dist_init(msm_amd_ctx* ctx, int rank, int world, const uint8_t* id12
         return MSM_AMD_EHIP;
     }
     // Sharded calls keep up to four small accumulations in flight on four streams; with HIP's default of four hardware queues they
-    // share queues with the sort streams (8-way shard: 0.82 instead of 0.58 ms per call).  The variable is read
+    // share queues with the sort streams (8-way shard, round 1: 0.82 instead of 0.58 ms per call).  The variable is read
     // when the HIP runtime starts, i.e. before this context existed: it cannot be set from here, only checked.
     if (world > 4) {
         const char* q = getenv("GPU_MAX_HW_QUEUES");
         if (!q || atoi(q) < 8)
             fprintf(stderr, "msm_amd: world = %d but GPU_MAX_HW_QUEUES is %s: export GPU_MAX_HW_QUEUES=8 before the process starts "
-                            "(sharded calls run ~40 %% slower with four hardware queues)\n", world, q ? q : "unset");
+                            "(sharded calls in flight may share hardware queues with the sort stream and serialise)\n", world, q ? q : "unset");
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     msm_nccl_id id;
