@@ -292,7 +292,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const bool e32 = sg.fbits + 1 + sg.idxbits <= 32;     // 4-byte partition entries {fine key | sign | index}
         // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
         // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
-        const bool wide = nv >= (1u << 19);
+        // (a rank of a many-way shard keeps four calls in flight: their 1024-lane, 100-KB sort workgroups wait for whole CUs to drain
+        // of the other calls' long-running waves -- 0.74 -> 0.70 ms per call at 8 ranks with the small tiles, 2 % the other way at 4)
+        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4);
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
@@ -1060,6 +1062,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size
     if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A
     if (!strcmp(name, "acc_variant")) { ctx->acc_variant = value; return 0; }   // experiments: 1 = two-chain build, 2 = chained build, 0 = by launch size
     if (!strcmp(name, "splitk_lanes")) { ctx->splitk_lanes = value ? value : 5u * 1024u * 64u; return 0; }
