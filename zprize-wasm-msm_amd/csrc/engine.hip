@@ -294,7 +294,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
         // (a rank of a many-way shard keeps four calls in flight: their 1024-lane, 100-KB sort workgroups wait for whole CUs to drain
         // of the other calls' long-running waves -- 0.74 -> 0.70 ms per call at 8 ranks with the small tiles, 2 % the other way at 4)
-        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4);
+        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4);   // (also at n = 2^22: 2.19 -> 2.00 ms, and 2^26: 24.7 -> 24.2)
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
