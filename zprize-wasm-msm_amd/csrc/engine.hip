@@ -292,9 +292,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const bool e32 = sg.fbits + 1 + sg.idxbits <= 32;     // 4-byte partition entries {fine key | sign | index}
         // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
         // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
-        // (a rank of a many-way shard keeps four calls in flight: their 1024-lane, 100-KB sort workgroups wait for whole CUs to drain
-        // of the other calls' long-running waves -- 0.74 -> 0.70 ms per call at 8 ranks with the small tiles, 2 % the other way at 4)
-        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4);   // (also at n = 2^22: 2.19 -> 2.00 ms, and 2^26: 24.7 -> 24.2)
+        // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
+        // 100 KB of LDS has to wait for a whole CU to drain of the long-running accumulation waves of the calls already in flight: with
+        // another call pending the small tiles give the better THROUGHPUT up to n = 2^22 (n = 2^20: 2.59-2.60 against 2.62-2.63 ms per
+        // MSM, 2^22: 10.80 against 10.95; equal from 2^24), and for the ranks of a many-way shard, which keep four calls in flight, at
+        // every size (8 ranks: n = 2^20 0.74 -> 0.70 ms per call, 2^22 2.19 -> 2.00, 2^26 24.7 -> 24.2; 2 % the other way at 4 ranks).
+        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
