@@ -55,7 +55,7 @@ enum {
                                    SRS of a prover); the scalars are a host buffer copied over PCIe by every call    */
     MSM_AMD_BASES_IN_SUBGROUP = 16 /* the caller vouches that every base lies in the order-r subgroup (what
                                    msm_amd_batch_in_group_affine checks; true of any SRS).  Allows the engine's GLV schedule
-                                   (BLS12-381 G1, 98304 <= n <= 2^17), which reduces scalars mod r and uses the endomorphism: correct in
+                                   (BLS12-381 G1, 98304 <= n <= 2^18), which reduces scalars mod r and uses the endomorphism: correct in
                                    the subgroup only.  Without the flag the result is the reference's for ANY points of the curve. */
 };
 
@@ -251,7 +251,7 @@ int msm_amd_glv_preprocess(msm_amd_ctx *ctx, uint32_t flags, const void *points,
 /* The split the engine itself applies inside BLS12-381 G1 MSMs (not a reference export; exposed so that it can be
  * checked without a GPU): k == s * (k1 + k2*lambda) (mod r), |k1|, k2 < 2^127.  out32 = |k1| (16 bytes LE) || k2 (16 bytes);
  * *sign bit 0 = the P term is negative, bit 1 = the phi(P) term is negative.  Host only.  Option "glv"
- * (msm_amd_set_option): 0 = never split, 1 = where it pays (default: 98304 <= n <= 2^17), 2 = whenever it applies (n >= 1024; forces 16-bit windows).      */
+ * (msm_amd_set_option): 0 = never split, 1 = where it pays (default: 98304 <= n <= 2^18), 2 = whenever it applies (n >= 1024; forces 16-bit windows).      */
 int msm_amd_glv_split(const uint8_t *scalar32, uint8_t *out32, uint32_t *sign);
 
 /* ---- device memory + measurement utilities (bench / tests) ------------------------------------- */

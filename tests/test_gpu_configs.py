@@ -101,7 +101,7 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
 def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     """The reference's g1m_multiexpAffine is integer arithmetic on curve points: exact for points outside the order-r subgroup too.
     The engine's GLV schedule (k mod r, endomorphism) is not -- so it only runs for callers that pass MSM_AMD_BASES_IN_SUBGROUP.
-    n = 100000 sits in the range (16-bit windows: 98304 <= n <= 2^17) where the GLV schedule is the default for flagged calls; a
+    n = 100000 sits in the range (16-bit windows: 98304 <= n <= 2^18) where the GLV schedule is the default for flagged calls; a
     smaller n = 4500 (8-bit windows, no GLV schedule whatever the flag says) is checked as well."""
     import msm_amd
     curve, group, n = "bls12381", 1, 100000

@@ -201,14 +201,15 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // with k reduced mod r holds in the order-r subgroup only, while the reference's multiexp is plain integer arithmetic, exact for
     // ANY point of the curve (G1 has a ~2^126 cofactor).  Without the flag the engine keeps the reference's semantics.
     // 2n virtual items with 127-bit signed halves, 8 windows of 16 bits (k_glv_halves).  Same number of bucket
-    // additions, half the buckets.  It pays where the bucket reduction dominates (n <= 2^17: 8-15 % per call); from 2^18 up
+    // additions, half the buckets.  It pays where the bucket reduction dominates (98304 <= n <= 2^18: 10-15 % per call; below, 8-bit
+    // windows are faster still); from 2^19 up
     // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
     // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2
     // forces the path (tests, experiments).
     bool use_glv = false;
     if constexpr (GlvField<F>::value)
         use_glv = (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
-                  (a.n <= (1u << 17) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
+                  (a.n <= (1u << 18) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
     const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
         g.n = nv;
