@@ -406,7 +406,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
                 HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
                 HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
             }
-            const uint32_t big_grid = (uint32_t)std::min<size_t>(max_chunks, 4096);
+            const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
             HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
             k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, cpre);
             k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, desc);
@@ -418,8 +418,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
                 k_big_hist<uint2><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
             }
             k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
-            if (e32) k_big_scatter<uint32_t><<<big_grid, SORT_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
-            else k_big_scatter<uint2><<<big_grid, SORT_BLOCK, big_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
+            const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
+            if (e32) k_big_scatter<uint32_t><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            else k_big_scatter<uint2><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
         }
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);

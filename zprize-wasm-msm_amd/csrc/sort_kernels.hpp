@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
 //   k_big_scatter  per chunk: LDS counting sort, every (chunk, bucket) run reserves its place with one atomic on the bucket's
 //                  cursor and is stored by consecutive lanes
 constexpr int BIG_ITEMS = 32;
-constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries
+constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries (16384 were tried: no faster at n = 2^26, and 164 KB of LDS at 12 fine bits)
 
 __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t* __restrict__ cpre) {
     __shared__ uint32_t wsum[16];
@@ -584,8 +584,11 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __re
         bcursor[gb0 + i] = start + h[i];
     }
 }
+// (1024 lanes x 8 entries per chunk: the 82 KB of staging allow one workgroup per CU, and four waves per CU left the kernel waiting
+// on its own loads: 11.2 ms for 7 + 3.5 GB at n = 2^26)
+constexpr int BIGS_BLOCK = 1024, BIGS_ITEMS = BIG_CHUNK / BIGS_BLOCK;
 template <class E>
-__global__ void __launch_bounds__(SORT_BLOCK) k_big_scatter(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
+__global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
                                                              const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t* __restrict__ bcursor,
                                                              uint32_t* __restrict__ sorted) {
     extern __shared__ uint32_t smem_u32[];
@@ -594,36 +597,43 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_scatter(const E* __restrict_
     uint32_t* gb = smem_u32 + nf;           // [nf] global position of the chunk's run of each bucket
     uint32_t* stage = smem_u32 + 2 * nf;    // [BIG_CHUNK]
     uint32_t* spos = stage + BIG_CHUNK;     // [BIG_CHUNK]
-    __shared__ uint32_t wsum[SORT_BLOCK / 64];
+    __shared__ uint32_t wsum[BIGS_BLOCK / 64];
     const uint32_t total = cpre[sg.nbins], t = threadIdx.x;
-    for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin, and the chunks of one span write 16-byte runs into the same ~1 MB of
+    // `sorted` (2048 buckets x 4 entries per chunk at c = 20).  Spread over eight L2s those partial lines each go to HBM on their own;
+    // with XCD x taking the x-th eighth of the chunk list, consecutive chunks of a span meet in ONE L2 and leave it as whole lines
+    // (the grid is a multiple of 8).
+    const uint32_t nx = 8, per = (total + nx - 1) / nx, x = blockIdx.x % nx, slots = gridDim.x / nx;
+    for (uint32_t q = blockIdx.x / nx; q < per; q += slots) {
+        const uint32_t it = x * per + q;
+        if (it >= total) break;   // (uniform over the workgroup)
         const uint2 d = desc[it];
         const uint32_t cn = min(binstart[d.x + 1], d.y + BIG_CHUNK) - d.y;
         const uint32_t gb0 = (d.x / sg.cb) * half + ((d.x % sg.cb) << sg.fbits);
-        for (uint32_t i = t; i < nf; i += SORT_BLOCK) th[i] = 0;
+        for (uint32_t i = t; i < nf; i += BIGS_BLOCK) th[i] = 0;
         __syncthreads();
-        E e[BIG_ITEMS];
-        uint32_t rank[BIG_ITEMS];
+        E e[BIGS_ITEMS];
+        uint32_t rank[BIGS_ITEMS];
 #pragma unroll
-        for (int k = 0; k < BIG_ITEMS; ++k) {
-            const uint32_t s = k * SORT_BLOCK + t;
+        for (int k = 0; k < BIGS_ITEMS; ++k) {
+            const uint32_t s = k * BIGS_BLOCK + t;
             if (s < cn) e[k] = tmp[d.y + s];
         }
 #pragma unroll
-        for (int k = 0; k < BIG_ITEMS; ++k) {
-            const uint32_t s = k * SORT_BLOCK + t;
+        for (int k = 0; k < BIGS_ITEMS; ++k) {
+            const uint32_t s = k * BIGS_BLOCK + t;
             if (s < cn) rank[k] = atomicAdd(&th[entry_fine(e[k], sg.idxbits)], 1u);
         }
         __syncthreads();
-        for (uint32_t i = t; i < nf; i += SORT_BLOCK) {
+        for (uint32_t i = t; i < nf; i += BIGS_BLOCK) {
             const uint32_t v = th[i];
             gb[i] = v ? atomicAdd(&bcursor[gb0 + i], v) : 0u;
         }
         __syncthreads();
-        block_exclusive_scan(th, nf, wsum);
+        block_exclusive_scan<BIGS_BLOCK>(th, nf, wsum);
 #pragma unroll
-        for (int k = 0; k < BIG_ITEMS; ++k) {
-            const uint32_t s = k * SORT_BLOCK + t;
+        for (int k = 0; k < BIGS_ITEMS; ++k) {
+            const uint32_t s = k * BIGS_BLOCK + t;
             if (s < cn) {
                 const uint32_t f = entry_fine(e[k], sg.idxbits), slot = th[f] + rank[k];
                 stage[slot] = entry_sorted(e[k], sg.idxbits);
@@ -631,7 +641,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_scatter(const E* __restrict_
             }
         }
         __syncthreads();
-        for (uint32_t s = t; s < cn; s += SORT_BLOCK) sorted[spos[s]] = stage[s];
+        for (uint32_t s = t; s < cn; s += BIGS_BLOCK) sorted[spos[s]] = stage[s];
         __syncthreads();
     }
 }
