@@ -541,11 +541,15 @@ void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
-                            uint32_t tail_block) {
-    k_accumulate_tail<F><<<1024, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
+                            uint32_t tail_block, bool tail_expected) {
+    // All three loop over whatever was queued with any grid.  When nothing is expected (random scalars practically never overflow a
+    // segment) the grids are small: a launch ends when its LAST workgroup has found the queue empty, and on a chip whose SIMDs are full
+    // of other calls' accumulation waves every workgroup waits for register room -- the empty 1024-workgroup launch took 55 us there.
+    const uint32_t g_acc = tail_expected ? 1024u : 16u, g_blk = tail_expected ? 64u : 4u, g_lane = tail_expected ? 512u : 8u;
+    k_accumulate_tail<F><<<g_acc, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
     constexpr uint32_t T = UKind<F>::type::LANES;   // tail_block and rblock count LOGICAL lanes (points); a point takes T threads
-    k_combine_tail<F><<<64, tail_block * T, (size_t)tail_block * T * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
-    k_combine_tail_lanes<F><<<512, 64, 0, st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
+    k_combine_tail<F><<<g_blk, tail_block * T, (size_t)tail_block * T * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
+    k_combine_tail_lanes<F><<<g_lane, 64, 0, st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
 }
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
@@ -577,7 +581,7 @@ uint32_t lanes_per_point() {
     template void launch_join_slices<F>(hipStream_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_TAIL(F)                                                                                                              \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
-                                            uint32_t, void*, void*, void*, uint8_t*, uint32_t);
+                                            uint32_t, void*, void*, void*, uint8_t*, uint32_t, bool);
 #define MSM_INSTANTIATE_REDUCE(F)                                                                                                            \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*, const uint32_t*, \
                                           const uint32_t*, uint32_t, uint32_t); \

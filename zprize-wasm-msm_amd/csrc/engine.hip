@@ -36,7 +36,7 @@ void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
-                            uint32_t tail_block);
+                            uint32_t tail_block, bool tail_expected);
 template <class F>
 void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
@@ -461,6 +461,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             while (k & (k - 1)) k &= k - 1;
         return std::max(k, 1u);
     };
+    // segments are expected for the tail kernels when recent calls queued some (skewed scalars), when the segment length is forced,
+    // and when the top window is only partly filled (few, dense buckets; the last rank of a 254-bit field)
+    const bool tail_expected = ctx->skew_hint.load() > 0 || ctx->force_seg != 0 || (g.nbits % g.c) != 0;
     const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
     const bool small_acc = ctx->acc_stream ? ctx->acc_stream == 1 : (NB < 5u * 1024u * 64u && !split_mode);
     st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
@@ -524,7 +527,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         }
         launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
-                                   (uint8_t*)sl->d_segout.p, tail_block);
+                                   (uint8_t*)sl->d_segout.p, tail_block, tail_expected);
         return 0;
     };
     if (int rc = accumulate(order, split, k_first)) return rc;
