@@ -86,7 +86,12 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
         for (uint32_t cand : {16u, 19u, 20u}) {
             if (cand > nbits) continue;
             const uint32_t w = (nbits + cand - 1) / cand;   // windows that receive scalar bits (a further carry-only window is negligible)
-            const uint64_t cost = (uint64_t)((w + nshards - 1) / nshards) * ((uint64_t)n + 6ull * (1ull << (cand - 1)));
+            uint64_t cost = (uint64_t)((w + nshards - 1) / nshards) * ((uint64_t)n + 6ull * (1ull << (cand - 1)));
+            // a top window of fewer than 12 bits (c = 19 over 256 bits: 9) has a few hundred buckets of n / 2^tb entries each, which go
+            // through the tail kernels at half the efficiency: count it twice (n = 2^24, ms per MSM at c = 19 | 20: BN254 20.8 | 20.2,
+            // BLS12-381 40.5 | 37.8 -- k_accumulate_tail + k_combine_tail took 2.6 of BN254's 20.8)
+            const uint32_t tb = nbits - (w - 1) * cand;
+            if (tb < 12 && tb < cand) cost += n;
             if (cost < best) {
                 best = cost;
                 c = cand;
