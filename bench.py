@@ -27,7 +27,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TMADS = 36.3         # v_mad_u64_u32 per second, measured at 2.4 GHz (profiles/r01_valu_rates_microbench.txt)
 # v_mad_u64_u32 per XYZZ mixed addition in the bucket kernels (6 products + 2 squarings + one fused two-product reduction):
 # NL-limb product = 2 NL^2, squaring = NL(NL+1)/2 + NL^2, fused = 3 NL^2; BLS12-381: NL = 14, BN254: NL = 9 (field_u.hpp)
-MADS_PER_ADD = {("bls12381", 1): 6 * 392 + 2 * 301 + 588, ("bn128", 1): 6 * 162 + 2 * 126 + 243}
+# G2 (an Fp2 element on a lane pair, field_u.hpp Fp2d): per LANE a product is one double-width accumulation (2 NL^2 + NL^2 for its
+# reduction), a square one single-width product (2 NL^2; BN254's tight radix squares by the product), the fused form four half
+# products and one reduction (5 NL^2); an addition occupies two lanes.
+MADS_PER_ADD = {("bls12381", 1): 6 * 392 + 2 * 301 + 588, ("bn128", 1): 6 * 162 + 2 * 126 + 243,
+                ("bls12381", 2): 2 * (6 * 588 + 2 * 392 + 980), ("bn128", 2): 2 * (6 * 243 + 2 * 243 + 405)}
+VALU_PEAK_IDEAL_TMADS = 39.3   # the same chip at an ideal 4.0 cycles per wave-instruction: 1024 SIMDs x 16 lanes x 2.4 GHz
 
 
 def uniform_scalars_mod_r(n, seed):
@@ -75,18 +80,27 @@ def launch_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll all children: the first one to exit non-zero (or the deadline) ends the job -- the others would sit in a collective until
+    # the launcher's own timeout (waiting for them in rank order noticed a crash of rank k > 0 only after rank 0 had timed out)
     rc = 0
     deadline = time.time() + float(os.environ.get("MSM_BENCH_LAUNCH_TIMEOUT", "1500"))
-    for p in procs:
-        try:
-            code = p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            code = -1
-        if code != 0 and rc == 0:
-            rc = code if code > 0 else 1
-            for q in procs:          # one rank failed or hung: the others would wait in the barrier for ever
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = (bad[0] if bad and bad[0] > 0 else 1)
+            for q in procs:
                 if q.poll() is None:
                     q.kill()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    for p in procs:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
     return rc
 
 
@@ -165,20 +179,30 @@ def main():
     eng = msm_amd.Engine(gpu_index)           # fails loudly without the HIP library / a GPU
     if args.window_bits:
         eng.set_window_bits(args.window_bits)
+    for kv in args.opt:      # (before the split of the inputs is planned: "dist_gw" changes it)
+        name, val = kv.split("=")
+        eng.set_option(name, int(val))
     C = eng.curve(args.curve)
     g = args.group
     jsz = C.jacobian_bytes(g)
 
-    # synthetic inputs, identical on every rank: P_i = k_i * G (GPU generated), scalars uniform in [0, r)
-    pts = C.gen_points(g, 0xC0FFEE02, n)
-    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02)
+    # synthetic inputs: P_i = k_i * G (GPU generated), scalars uniform in [0, r).  N = 1: all n of them.  N > 1: every rank generates
+    # and holds ONLY ITS SLICE of the points and scalars (gp point slices x gw window groups, msm_amd_dist_plan: 6 GiB of bases at
+    # n = 2^26 are 0.75 GiB per GPU at gp = 8) -- the placement a prover with a sharded SRS has; the ranks of one slice (gw > 1) hold
+    # the same slice.  MSM_BENCH_GW forces the number of window groups (gw = world: windows only, every rank holds everything).
+    if os.environ.get("MSM_BENCH_GW"):
+        eng.set_option("dist_gw", int(os.environ["MSM_BENCH_GW"]))
+    plan = eng.dist_plan(args.curve, g, 32, n, world, rank) if sharded else {"gp": 1, "gw": 1, "first": 0, "count": n}
+    first, count = plan["first"], plan["count"]
+    pts = C.gen_points(g, 0xC0FFEE02, count, first)
+    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02)[first:first + count]
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
     h_pts = h_sc = None
     if args.host_buffers:
         import numpy as np
-        h_pts = np.frombuffer(pts.download(n * C.affine_bytes(g)), dtype=np.uint8).copy()
+        h_pts = np.frombuffer(pts.download(count * C.affine_bytes(g)), dtype=np.uint8).copy()
         h_sc = np.ascontiguousarray(sc_host)
 
     # N > 1: the exchange of the window partials runs behind the C ABI (msm_amd_dist_*: the engine's own RCCL communicator, ONE
@@ -189,24 +213,44 @@ def main():
     if sharded:
         exchange = "torch.distributed all_gather_into_tensor (msm_amd.dist)"
         if backend == "nccl":
-            try:
-                box = [msm_amd.dist_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                eng.dist_init(rank, world, box[0])
-                exchange = "C ABI: msm_amd_multiexp_dist_async / msm_amd_dist_wait (ncclAllGather on the engine's own communicator)"
-            except msm_amd.MsmAmdError as e:
-                print(f"bench.py: msm_amd_dist_init failed on rank {rank} ({e}); exchanging through torch.distributed", file=sys.stderr)
+            # the ranks agree on the outcome: rank 0 broadcasts the id or a failure marker unconditionally, and the C-ABI exchange is
+            # used only if msm_amd_dist_init succeeded on EVERY rank (a rank falling back on its own would leave the others in
+            # ncclCommInitRank or in a collective nobody else enters)
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [msm_amd.dist_unique_id()]
+                except msm_amd.MsmAmdError as e:
+                    print(f"bench.py: msm_amd_dist_unique_id failed ({e})", file=sys.stderr)
+            dist.broadcast_object_list(box, src=0)
+            ok = 0
+            if box[0] is not None:
+                try:
+                    eng.dist_init(rank, world, box[0])
+                    ok = 1
+                except msm_amd.MsmAmdError as e:
+                    print(f"bench.py: msm_amd_dist_init failed on rank {rank} ({e})", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = "C ABI: msm_amd_multiexp_dist_local_async / msm_amd_dist_wait (ncclAllGather on the engine's own communicator)"
+            else:
+                if ok:
+                    eng.dist_destroy()
+                if rank == 0:
+                    print("bench.py: exchanging through torch.distributed on every rank", file=sys.stderr)
     cabi = bool(exchange and exchange.startswith("C ABI"))
+    gw = plan["gw"]
 
     def step():
         if cabi:
-            return C.multiexp_dist(g, pts, d_scalars, 32, n)
+            return C.multiexp_dist_local(g, pts, d_scalars, 32, count, n)
         if args.host_buffers:
             return C._multiexp(g, 0, pts if args.resident_bases else h_pts, h_sc, 32, n)
         if not sharded:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
-        # windows sharded over the ranks; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
-        return mdist.multiexp_sharded(C, g, pts, d_scalars, 32, n, device=xdev)
+        # this rank's windows of its slice; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
+        return mdist.gather_and_combine(args.curve, g, C.multiexp_shard(g, pts, d_scalars, 32, count, rank % gw, gw), xdev)
 
     def sync():
         torch.cuda.synchronize()
@@ -227,9 +271,6 @@ def main():
     # (tools/bench_shard.py on one GPU: 2 in flight is best up to 4 ranks, 4 at 8 ranks)
     depth = 1 if not pipelined else (args.depth or (2 if world <= 4 else 4))
     eng.set_option("slots", max(depth, 1))
-    for kv in args.opt:
-        name, val = kv.split("=")
-        eng.set_option(name, int(val))
 
     xch = mdist.PartialExchange(args.curve, g, device=xdev) if sharded else None
     gathering = []   # all_gathers started and not yet collected (at most one is left running behind the loop)
@@ -253,7 +294,7 @@ def main():
                 if not sharded:
                     inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
                 else:
-                    inflight.append(C.multiexp_dist_async(g, pts, d_scalars, 32, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, n, rank, world))
+                    inflight.append(C.multiexp_dist_local_async(g, pts, d_scalars, 32, count, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, count, rank % gw, gw))
                 if len(inflight) == depth:
                     res = finish(inflight.pop(0))
                     collect()
@@ -346,7 +387,8 @@ def main():
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
-                       "parallelism": "1 GPU" if not sharded else f"windows sharded over {world} GPUs + RCCL all_gather of partials",
+                       "parallelism": "1 GPU" if not sharded else f"{plan['gp']} point slices x {plan['gw']} window groups over {world} GPUs (every rank holds only its slice) + ONE RCCL all_gather of the partials",
+                       "split": None if not sharded else {"gp": plan["gp"], "gw": plan["gw"], "points_per_rank": count},
                        "exchange": exchange},
             "mode": (f"pipelined({depth}): {depth} calls in flight, every call collected inside the timed region" if pipelined else "one call at a time"),
             # the dominant kernel is integer-ALU bound: its roofline is the VALU issue rate of v_mad_u64_u32 (MADS_PER_ADD of them per
@@ -359,6 +401,8 @@ def main():
                           "frac": geom["entries"] * mads / (acc_ms * 1e-3) / 1e12 / VALU_PEAK_TMADS,
                           "frac_one_call_at_a_time": (geom["entries"] * mads / (acc_iso * 1e-3) / 1e12 / VALU_PEAK_TMADS) if acc_iso > 0 else None,
                           "mads_per_bucket_addition": mads,
+                          "peak_ideal": VALU_PEAK_IDEAL_TMADS, "frac_of_peak_ideal": geom["entries"] * mads / (acc_ms * 1e-3) / 1e12 / VALU_PEAK_IDEAL_TMADS,
+                          "peak_note": "peak = measured v_mad_u64_u32 rate (4.34 cycles per wave-instruction at 2.4 GHz); peak_ideal = 4.0 cycles",
                           "peak_source": "measured: tools/microbench/valu_rates.hip, profiles/r01_valu_rates_microbench.txt (v_mad_u64_u32, 2.4 GHz)",
                           "traffic": traffic, "traffic_note": "HBM-side bytes per launch from rocprofv3 --pmc: 1.6 x FETCH_SIZE + WRITE_SIZE -- the guide's x2 on FETCH_SIZE holds for streaming reads; for this kernel's access pattern (random 96-byte records, 16-byte loads) tools/microbench/gather_fetch.hip measures 1.58-1.64 (profiles/r02_gather_fetch_calibration.txt); measured on this workload only",
                           "avg_launch_ms": acc_ms, "avg_launch_ms_one_call_at_a_time": acc_iso,
@@ -370,7 +414,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
                           "avg_launch_ms_one_call_at_a_time": acc_iso}),
-            "roofline_scatter": {"kernels": "digits + coarse histogram + scan + coarse scatter + fine sort + population order (HBM-bound stage)", "bound": "hbm",
+            "roofline_scatter": {"kernels": "k_tile_hist + k_bin_scan + k_tile_scatter + k_fine_small (k_big_* for long spans) + k_order_hist + k_order_scatter (HBM-bound stage, csrc/sort_kernels.hpp)", "bound": "hbm",
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,

@@ -64,7 +64,8 @@ enum {
     MSM_AMD_OK = 0,
     MSM_AMD_EINVAL = -1,   /* bad argument (null pointer, scalar_size out of range, bad curve/group, misaligned device pointer) */
     MSM_AMD_EHIP = -2,     /* HIP runtime failure (no GPU, out of memory, launch failure) */
-    MSM_AMD_ENOMEM = -3
+    MSM_AMD_ENOMEM = -3,
+    MSM_AMD_EPEER = -4     /* multi-GPU call: another rank of the group failed its part (this rank's part was fine) */
 };
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -124,25 +125,45 @@ int msm_amd_multiexp_shard_async(msm_amd_ctx *ctx, int curve, int group, uint32_
 int msm_amd_combine(int curve, int group, const uint8_t *partials, uint32_t count, uint8_t *out);
 
 /* ---- multi-GPU: the exchange itself, RCCL over xGMI behind the C ABI (one process per GPU) ------------------------------
- * The reference's seam is its per-window export fnName_chunk (build_multiexp.js:96-104, :469), which its external caller fans out
- * to workers and recombines on the main thread; here the workers are the GPUs of one node.
+ * The reference offers two seams and a call is split along both: its per-window export fnName_chunk (build_multiexp.js:96-104, :469),
+ * which its external caller fans out to workers and recombines on the main thread, and the MSM's linearity over slices of the points
+ * (what that caller does above 2^22 points; :251-371 is one slice).  Here the workers are the GPUs of one node: the `world` ranks form
+ * gp point slices x gw window groups (gp * gw = world, chosen per call from the per-rank cost model; option "dist_gw" forces gw), rank
+ * r = p * gw + w computes the windows {k : k % gw == w} of slice p.
  *   rank 0:      msm_amd_dist_unique_id(id)           -> 128 bytes, handed to the other ranks by whatever channel the host has
  *   every rank:  msm_amd_dist_init(ctx, rank, world, id)   (collective: returns when all ranks have joined)
- *                msm_amd_multiexp_dist(ctx, ...)      -> this rank's windows on this rank's GPU, ONE ncclAllGather of
- *                                                        world x (144 | 96 | 288 | 192) bytes, the partials added on the host:
- *                                                        the same normalised result on every rank
+ *                msm_amd_multiexp_dist(ctx, ...)      -> every rank passes ALL n points and scalars (resident or host memory) and works
+ *                                                        on its part of them; ONE ncclAllGather of world x 304 bytes (status + Jacobian
+ *                                                        partial), the partials added on the host: the same normalised result on every rank
+ *                msm_amd_dist_plan(ctx, ..., n, 0, 0, &gp, &gw, &first, &count) + msm_amd_multiexp_dist_local(ctx, ..., bases_local, scalars_local, count, n)
+ *                                                     -> the same for a rank that holds only ITS slice [first, first + count) of the n
+ *                                                        points (6 GiB of bases at n = 2^26 become 0.75 GiB per GPU at gp = 8)
  *                msm_amd_dist_destroy(ctx)            (also done by msm_amd_destroy)
- * The asynchronous pair keeps several sharded calls in flight per rank (up to `slots`); every rank must collect its tickets in
- * the same order.  RCCL is dlopen'ed on first use.  With more than four ranks export GPU_MAX_HW_QUEUES=8 before the process
+ * The asynchronous pair keeps several calls in flight per rank (up to `slots`).  Every rank must SUBMIT the same calls in the same
+ * order; the exchanges then happen in that order on every rank, whatever the order and the threads in which the tickets are waited
+ * for (every ticket must be waited for: a later one waits for its turn).  A call whose part cannot be queued or fails on one rank still
+ * completes on all: that rank gets its own error, the others MSM_AMD_EPEER -- nobody is left waiting in a collective.
+ * RCCL is dlopen'ed on first use.  With more than four ranks export GPU_MAX_HW_QUEUES=8 before the process
  * starts (read by the HIP runtime at start-up; msm_amd_dist_init warns when it is missing).                                    */
 int msm_amd_dist_unique_id(uint8_t *out128);
 int msm_amd_dist_init(msm_amd_ctx *ctx, int rank, int world, const uint8_t *id128);
 int msm_amd_dist_destroy(msm_amd_ctx *ctx);
 int msm_amd_dist_info(const msm_amd_ctx *ctx, int *rank, int *world); /* world = 0: not in a group */
+/* the split of a call of n points over a group of `world` ranks and the slice of the points rank `rank` = p * gw + w takes
+ * (world = 0: this context's own group and rank) */
+int msm_amd_dist_plan(const msm_amd_ctx *ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t rank,
+                      uint32_t *gp, uint32_t *gw, uint32_t *first, uint32_t *count);
 int msm_amd_multiexp_dist(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, const void *scalars,
                           uint32_t scalar_size, uint32_t n, uint8_t *out);
 int msm_amd_multiexp_dist_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
                                 const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);
+/* bases_local / scalars_local: the n_local points of this rank's slice; n_local must equal the `count` of msm_amd_dist_plan for
+ * n_total (checked: the split depends on the context's options, which must not change between plan and call) */
+int msm_amd_multiexp_dist_local(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases_local,
+                                const void *scalars_local, uint32_t scalar_size, uint32_t n_local, uint32_t n_total, uint8_t *out);
+int msm_amd_multiexp_dist_local_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases_local,
+                                      const void *scalars_local, uint32_t scalar_size, uint32_t n_local, uint32_t n_total,
+                                      uint64_t *ticket);
 int msm_amd_dist_wait(msm_amd_ctx *ctx, int curve, int group, uint64_t ticket, uint8_t *out);
 
 /* ---- reference-named wrappers (host pointers) ------------------------------------------------- */
@@ -261,6 +282,8 @@ int msm_amd_h2d(msm_amd_ctx *ctx, void *dev_dst, const void *host_src, size_t by
 int msm_amd_d2h(msm_amd_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes);
 /* Fills dev_out with n affine points k_i * G (k_i from a counter-based PRNG of `seed`): synthetic bases. */
 int msm_amd_gen_points(msm_amd_ctx *ctx, int curve, int group, uint64_t seed, uint32_t n, void *dev_out);
+/* points [first, first + n) of the same sequence: a rank of a multi-GPU group generates only its slice */
+int msm_amd_gen_points_range(msm_amd_ctx *ctx, int curve, int group, uint64_t seed, uint32_t first, uint32_t n, void *dev_out);
 /* Per-stage GPU time of the last call on this context, HIP events on the engine's stream (ms).
  * Order: [0] total GPU, [1] digits+histogram, [2] scan+order, [3] scatter, [4] bucket accumulation,
  *        [5] bucket reduction, [6] host combine (wall), [7] bases conversion (Jacobian input only).

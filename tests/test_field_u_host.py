@@ -19,3 +19,14 @@ def test_field_u_against_host_field(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(": ok") == 4, r.stdout
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_regrown_buffer_is_not_taken_for_still_zero(tmp_path):
+    """csrc/engine_ctx.hpp: ensure() through an allocator that returns the same address when a buffer grows (host only)."""
+    exe = tmp_path / "test_devbuf"
+    subprocess.run(["hipcc", "--cuda-host-only", "-O0", "-std=c++17", "-I", os.path.join(ROOT, "zprize-wasm-msm_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "test_devbuf.hip"), "-o", str(exe)], check=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "devbuf: ok" in r.stdout

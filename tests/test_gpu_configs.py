@@ -65,9 +65,24 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
         full = _call(eng, C, group, pts.ptr, sp, n)
         geom = eng.geometry()
         assert geom["entries"] > n * (geom["windows"] - 2)     # (nearly) every window of every pair was scattered
-        # (1) the multi-GPU decomposition on one GPU
+        # (1) the multi-GPU decompositions on one GPU: eight window shards of all the points; the hybrid form the engine plans for
+        #     eight ranks (gp point slices x gw window groups, every rank on a view of its slice only)
         parts = b"".join(C.multiexp_shard(group, pts, sc, 32, n, r, 8) for r in range(8))
         assert msm_amd.combine(curve, group, parts) == full
+        from msm_amd import dist as mdist
+        plan = eng.dist_plan(curve, group, 32, n, 8, 0)
+        hybrid = []
+        for r in range(8):
+            first, count = mdist.slice_of(n, plan["gp"], r // plan["gw"])
+            hybrid.append(C.multiexp_shard(group, pts.view(first * asz, count * asz), sc.reshape(-1)[first * 32:(first + count) * 32], 32, count,
+                                           r % plan["gw"], plan["gw"]))
+        assert msm_amd.combine(curve, group, b"".join(hybrid)) == full
+        if plan["gp"] != 2:          # and a split that cuts both ways
+            hybrid = []
+            for r in range(8):
+                first, count = mdist.slice_of(n, 2, r // 4)
+                hybrid.append(C.multiexp_shard(group, pts.view(first * asz, count * asz), sc.reshape(-1)[first * 32:(first + count) * 32], 32, count, r % 4, 4))
+            assert msm_amd.combine(curve, group, b"".join(hybrid)) == full
         # (2) point slices: uneven cut, so the two halves see different n (and possibly different window sizes)
         cut = (n // 3) | 1
         lo = _call(eng, C, group, pts.ptr, sp, cut)
@@ -346,7 +361,8 @@ def test_bench_gpus_2_reports_two_ranks():
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 6 and line["value"] > 0
-    assert "sharded over 2" in line["config"]["parallelism"]
+    assert "over 2 GPUs" in line["config"]["parallelism"]
+    assert line["config"]["split"]["gp"] * line["config"]["split"]["gw"] == 2
 
 
 def test_dist_entry_points_with_a_group_of_one(orc):

@@ -1,0 +1,229 @@
+"""GPU tests added in round 3 (run with -m gpu on the MI355X box), all through the C ABI:
+  * the hybrid split of a multi-GPU call -- gp point slices x gw window groups -- summed on one GPU, for every factorisation of
+    2, 3, 4, 6 and 8 ranks, ragged slices included; the split the engine itself plans (msm_amd_dist_plan);
+  * the exchange of a group: tickets waited for in any order and from several threads still exchange in submission order,
+    G1 and G2 calls mixed; a call that fails on this rank completes with its own error and leaves the sequence intact;
+  * window digits of exactly 2^(c-1) at c = 20 and 21 (the packed (bucket, rank) word of the coarse partition);
+  * the sort's bin histogram growing between calls of one context (small-bin calls first, then a call with more bins)."""
+import ctypes
+import threading
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import msm_amd
+    e = msm_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def orc(oracle_lib):
+    return oracle_lib
+
+
+def _hybrid_parts(C, group, bases, scalars, n, gp, gw, asz):
+    """the world = gp * gw partials of the hybrid decomposition, computed one after the other on this GPU"""
+    from msm_amd import dist as mdist
+    parts = []
+    for r in range(gp * gw):
+        first, count = mdist.slice_of(n, gp, r // gw)
+        parts.append(C.multiexp_shard(group, bases[first * asz:(first + count) * asz], scalars[first * 32:(first + count) * 32], 32, count, r % gw, gw))
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 5000), ("bn128", 1, 130000), ("bls12381", 2, 1500), ("bls12381", 1, 7)])
+def test_hybrid_shards_sum_to_full(eng, orc, curve, group, n):
+    """Every (gp, gw) with gp * gw in {2, 3, 4, 6, 8}: the partials of the point slices x window groups add up to the oracle's result
+    (slices of ceil(n / gp): ragged for most n here, empty ones at n = 7; slices on either side of the 8-bit / 16-bit window rule)."""
+    import msm_amd
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    asz = C.affine_bytes(group)
+    bases, scalars = gu.random_case(curve, group, f"gpu:hybrid:{curve}:{group}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    for world in (2, 3, 4, 6, 8):
+        for gw in range(1, world + 1):
+            if world % gw:
+                continue
+            parts = _hybrid_parts(C, group, bases, scalars, n, world // gw, gw, asz)
+            assert msm_amd.combine(curve, group, parts) == exp, (world, gw)
+
+
+def test_planned_split_is_a_factorisation_and_covers_the_points(eng):
+    """msm_amd_dist_plan for worlds of 1..8 ranks over the sizes of the sweep: gp * gw = world, the slices of the ranks with w = 0
+    tile [0, n), ranks of one slice agree on it, and option dist_gw forces the window groups."""
+    for logn in (10, 16, 18, 20, 22, 24, 26):
+        n = (1 << logn) + 3
+        for world in range(1, 9):
+            covered = 0
+            for rank in range(world):
+                p = eng.dist_plan("bls12381", 1, 32, n, world, rank)
+                assert p["gp"] * p["gw"] == world
+                from msm_amd import dist as mdist
+                assert (p["first"], p["count"]) == mdist.slice_of(n, p["gp"], rank // p["gw"])
+                if rank % p["gw"] == 0:
+                    assert p["first"] == covered
+                    covered += p["count"]
+            assert covered == n
+    try:
+        eng.set_option("dist_gw", 2)
+        p = eng.dist_plan("bls12381", 1, 32, 1 << 20, 8, 5)
+        assert (p["gp"], p["gw"]) == (4, 2) and p["first"] == 2 * (1 << 18) and p["count"] == 1 << 18
+        p = eng.dist_plan("bls12381", 1, 32, 1 << 20, 3, 0)         # 2 does not divide 3: the option is ignored
+        assert p["gp"] * p["gw"] == 3
+    finally:
+        eng.set_option("dist_gw", 0)
+    # big inputs are cut along the points (every rank a full-size MSM of its slice: profiles/r03_shard_per_rank_table.txt)
+    assert eng.dist_plan("bls12381", 1, 32, 1 << 26, 8, 0)["gp"] == 8
+
+
+def test_exchanges_follow_submission_order_whatever_the_waits_do(orc):
+    """A group of one (all a one-GPU box can hold) with four slots: G1, G2, G1, G1 calls submitted, then waited for in REVERSE order
+    from four threads.  Each wait blocks until the exchanges of the calls submitted before it are done -- the order every rank of
+    a real group shares -- and every result is right.  (With more ranks the same property keeps two promises of a Node host from
+    meeting each other's all-gather.)"""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("slots", 4)
+        eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        cases = []
+        for k, (curve, group, n) in enumerate((("bls12381", 1, 3000), ("bls12381", 2, 700), ("bls12381", 1, 120000), ("bls12381", 1, 9))):
+            bases, scalars = gu.random_case(curve, group, f"gpu:order:{k}", n)
+            O = orc.Oracle(curve, group)
+            cases.append((group, bases, scalars, n, O.normalize(O.multiexp_affine(bases, scalars, 32, n))))
+        C = eng.curve("bls12381")
+        tickets = [C.multiexp_dist_async(g, b, s, 32, n) for g, b, s, n, _ in cases]
+        done, got = [], [None] * 4
+        lock = threading.Lock()
+
+        def waiter(k):
+            got[k] = tickets[k].wait()
+            with lock:
+                done.append(k)
+
+        threads = []
+        for k in (3, 2, 1, 0):
+            t = threading.Thread(target=waiter, args=(k,))
+            t.start()
+            threads.append(t)
+            if k:
+                t.join(timeout=0.3)
+                assert t.is_alive(), f"ticket {k} completed before the exchange of ticket 0"     # its turn has not come
+        for t in threads:
+            t.join(timeout=120)
+            assert not t.is_alive()
+        assert done == [0, 1, 2, 3]
+        for k, (_, _, _, _, exp) in enumerate(cases):
+            assert got[k] == exp, k
+        # a ticket is collected once
+        with pytest.raises(msm_amd.MsmAmdError, match="unknown or already collected"):
+            tickets[0].wait()
+    finally:
+        eng.close()
+
+
+def test_a_failed_part_completes_the_exchange_and_the_sequence_goes_on(orc):
+    """This rank's part of a call cannot be queued (its slice length contradicts the plan; no free slot): the call still gets a
+    ticket and takes part in its exchange with a failure mark -- on a real group the peers return MSM_AMD_EPEER instead of hanging in
+    the collective -- the error comes back from the wait, and the calls around it are unaffected."""
+    import msm_amd
+    curve, group, n = "bn128", 1, 2500
+    eng = msm_amd.Engine(0)
+    try:
+        eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, "gpu:distfail", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        plan = eng.dist_plan(curve, group, 32, n)
+        assert plan == {"gp": 1, "gw": 1, "first": 0, "count": n}
+        good1 = C.multiexp_dist_local_async(group, bases, scalars, 32, n, n)
+        bad = C.multiexp_dist_local_async(group, bases, scalars, 32, n - 1, n)       # accepted: the failure travels with the exchange
+        assert good1.wait() == exp
+        good2 = C.multiexp_dist_local_async(group, bases, scalars, 32, n, n)
+        with pytest.raises(msm_amd.MsmAmdError, match="slice of 2500 points is 2500") as ei:
+            bad.wait()
+        assert ei.value.code == msm_amd.EINVAL
+        assert good2.wait() == exp
+        # every slot taken (two by default): the third call is refused by the engine, and says so at its wait
+        t = [C.multiexp_dist_async(group, bases, scalars, 32, n) for _ in range(3)]
+        assert t[0].wait() == exp and t[1].wait() == exp
+        with pytest.raises(msm_amd.MsmAmdError, match="every slot"):
+            t[2].wait()
+        assert C.multiexp_dist(group, bases, scalars, 32, n) == exp
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("c", [20, 21, 16, 9])
+def test_digits_of_exactly_half_the_window(eng, orc, c):
+    """A window digit equal to 2^(c-1) is the largest magnitude a signed c-bit digit takes and lands in the LAST bucket of its window.
+    At c = 21 that is 2^20: packed as magnitude << 12 | rank it left the 32-bit word (entry dropped, or LDS indexed out of bounds);
+    the coarse partition now packs the bucket index.  Scalars are built so that many windows hold exactly 2^(c-1), with and without a
+    carry from the window below (2^(c-1) - 1 plus carry), next to random ones."""
+    import random
+    curve, group, n = "bls12381", 1, 6000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, rnd_scalars = gu.random_case(curve, group, f"gpu:half:{c}", n)
+    rnd = random.Random(f"half:{c}")
+    half = 1 << (c - 1)
+    W = 255 // c
+    sc = bytearray(rnd_scalars)
+    for i in range(0, n, 2):
+        v = 0
+        for w in range(W):
+            pick = rnd.randrange(4)
+            d = half if pick == 0 else (half - 1 if pick == 1 else (half + 1 if pick == 2 else rnd.randrange(1 << c)))
+            v |= d << (w * c)
+        sc[32 * i:32 * i + 32] = (v % (1 << 255)).to_bytes(32, "little")
+    scalars = bytes(sc)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    try:
+        eng.set_window_bits(c)
+        for big in (0, 1):
+            eng.set_option("sort_big", big)
+            assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp, (c, big)
+        assert eng.geometry()["c"] == c
+    finally:
+        eng.set_window_bits(0)
+        eng.set_option("sort_big", 0)
+
+
+def test_bin_histogram_grows_between_calls(orc):
+    """Deterministic form of the sequence behind round 2's one GPU fault: a fresh context makes dozens of calls with the 33 bins of
+    8-bit windows, then its first call with more bins than the histogram holds (a 3-way shard at 16-bit windows, tiny n; then full
+    calls at 16 and 20 bits).  Whether the allocator hands the regrown buffer back at the old address or not, the new bins must be
+    cleared (the mark is keyed on the buffer's allocation count; host-only twin: tests/host/test_devbuf.hip)."""
+    import msm_amd
+    curve, group = "bls12381", 1
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        for k in range(40):
+            n = 5 + 11 * k
+            bases, scalars = gu.random_case(curve, group, f"gpu:regrow:{k}", n)
+            assert C.g1m_multiexpAffine(bases, scalars, 32, n) == O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+            assert eng.geometry()["c"] == 8
+        n = 7
+        bases, scalars = gu.random_case(curve, group, "gpu:regrow:late", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        eng.set_window_bits(16)
+        parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, r, 3) for r in range(3))
+        assert msm_amd.combine(curve, group, parts) == exp
+        for c in (16, 20, 13, 21):
+            eng.set_window_bits(c)
+            n = 3000
+            bases, scalars = gu.random_case(curve, group, f"gpu:regrow:c{c}", n)
+            assert C.g1m_multiexpAffine(bases, scalars, 32, n) == O.normalize(O.multiexp_affine(bases, scalars, 32, n)), c
+    finally:
+        eng.close()

@@ -33,6 +33,16 @@ def one_pass(group, bench_args, tag, idx):
             s = acc.setdefault(k, [0, 0.0])
             s[0] += 1
             s[1] += float(r["Counter_Value"])
+    # launch durations of the same pass (kernel trace): the effective clock of a kernel is GRBM_GUI_ACTIVE / 8 XCDs / duration
+    for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            try:
+                k = (r["Kernel_Name"], "duration_ns")
+                s = acc.setdefault(k, [0, 0.0])
+                s[0] += 1
+                s[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
     return {k: (v[0], v[1] / v[0]) for k, v in acc.items()}
 
 
@@ -54,6 +64,10 @@ def main():
             d[ctr] = mean
     doc = {"command": "rocprofv3 --kernel-trace --pmc <group> (one pass per group) -- python3 bench.py --no-cpu-baseline --no-pipeline " + " ".join(bench_args),
            "groups": groups, "units": "mean per launch, as rocprofv3 reports", "kernels": res}
+    json.dump(doc, open(out_json, "w"), indent=1)
+    for k, v in res.items():
+        if "GRBM_GUI_ACTIVE" in v and v.get("duration_ns"):
+            v["effective_clock_GHz"] = v["GRBM_GUI_ACTIVE"] / 8.0 / v["duration_ns"]
     json.dump(doc, open(out_json, "w"), indent=1)
     for k, v in res.items():
         if "accumulate" in k:

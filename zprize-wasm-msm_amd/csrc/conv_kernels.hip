@@ -299,11 +299,11 @@ MSM_HD uint64_t splitmix64(uint64_t x) {
     return x ^ (x >> 31);
 }
 template <class F>
-__global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed, uint32_t n, uint8_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed, uint32_t first, uint32_t n, uint8_t* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t k[4];
-    for (int j = 0; j < 4; ++j) k[j] = splitmix64(seed * 0x100000001B3ull + (uint64_t)i * 4 + j);
+    uint64_t k[4];   // the multiplier of point first + i of the sequence (a slice of it can be generated on its own)
+    for (int j = 0; j < 4; ++j) k[j] = splitmix64(seed * 0x100000001B3ull + ((uint64_t)first + i) * 4 + j);
     k[3] &= 0x3fffffffffffffffull;   // 254-bit multipliers
     if ((k[0] | k[1] | k[2] | k[3]) == 0) k[0] = 1;
     XYZZ<F> acc = XYZZ<F>::inf();
@@ -318,9 +318,9 @@ __global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed
 }  // namespace msm
 
 template <class F>
-static int gen_points_t(msm_amd_ctx* ctx, const Affine<F>& gen, uint64_t seed, uint32_t n, void* dev_out) {
+static int gen_points_t(msm_amd_ctx* ctx, const Affine<F>& gen, uint64_t seed, uint32_t first, uint32_t n, void* dev_out) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    k_gen_points<F><<<(n + 255) / 256, 256, 0, ctx->stream>>>(gen, seed, n, (uint8_t*)dev_out);
+    k_gen_points<F><<<(n + 255) / 256, 256, 0, ctx->stream>>>(gen, seed, first, n, (uint8_t*)dev_out);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
     return 0;
@@ -587,27 +587,30 @@ int msm_amd_glv_preprocess(msm_amd_ctx* ctx, uint32_t flags, const void* points,
 }
 
 int msm_amd_gen_points(msm_amd_ctx* ctx, int curve, int group, uint64_t seed, uint32_t n, void* dev_out) {
+    return msm_amd_gen_points_range(ctx, curve, group, seed, 0, n, dev_out);
+}
+int msm_amd_gen_points_range(msm_amd_ctx* ctx, int curve, int group, uint64_t seed, uint32_t first, uint32_t n, void* dev_out) {
     if (!ctx || !dev_out) return MSM_AMD_EINVAL;
     if (n == 0) return 0;
     if (curve == MSM_AMD_BLS12381 && group == 1) {
         using P = Bls12381Fp;
         Affine<Fp<P>> g{fp_from<P>(P::G1X), fp_from<P>(P::G1Y)};
-        return gen_points_t<Fp<P>>(ctx, g, seed, n, dev_out);
+        return gen_points_t<Fp<P>>(ctx, g, seed, first, n, dev_out);
     }
     if (curve == MSM_AMD_BN128 && group == 1) {
         using P = Bn254Fp;
         Affine<Fp<P>> g{fp_from<P>(P::G1X), fp_from<P>(P::G1Y)};
-        return gen_points_t<Fp<P>>(ctx, g, seed, n, dev_out);
+        return gen_points_t<Fp<P>>(ctx, g, seed, first, n, dev_out);
     }
     if (curve == MSM_AMD_BLS12381 && group == 2) {
         using P = Bls12381Fp;
         Affine<Fp2<P>> g{{fp_from<P>(P::G2X0), fp_from<P>(P::G2X1)}, {fp_from<P>(P::G2Y0), fp_from<P>(P::G2Y1)}};
-        return gen_points_t<Fp2<P>>(ctx, g, seed, n, dev_out);
+        return gen_points_t<Fp2<P>>(ctx, g, seed, first, n, dev_out);
     }
     if (curve == MSM_AMD_BN128 && group == 2) {
         using P = Bn254Fp;
         Affine<Fp2<P>> g{{fp_from<P>(P::G2X0), fp_from<P>(P::G2X1)}, {fp_from<P>(P::G2Y0), fp_from<P>(P::G2Y1)}};
-        return gen_points_t<Fp2<P>>(ctx, g, seed, n, dev_out);
+        return gen_points_t<Fp2<P>>(ctx, g, seed, first, n, dev_out);
     }
     msm_set_err(ctx, "unknown curve/group");
     return MSM_AMD_EINVAL;

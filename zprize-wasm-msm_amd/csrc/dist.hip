@@ -1,10 +1,13 @@
-// dist.hip -- the multi-GPU exchange behind the C ABI (the seam is the reference's per-window entry point
-// fnName_chunk, wasmcurves/src/build_multiexp.js:96-104, which its external caller fans out to workers and recombines).
+// dist.hip -- the multi-GPU exchange behind the C ABI.  The reference offers two seams, and a call is split along
+// both: its per-window entry point fnName_chunk (wasmcurves/src/build_multiexp.js:96-104, :469), which its external caller fans out
+// to workers, and the linearity of the MSM over slices of the points (what that caller does above 2^22 points; :251-371 is one slice).
 //
-// One process per GPU.  Rank r of `world` computes the windows {w : w mod world = r} of the same (bases, scalars) on its own
-// MI355X (msm_amd_multiexp_shard_async), which leaves ONE Jacobian partial, already weighted by 2^(c*w).  The partials -- 144 bytes
-// for BLS12-381 G1, at most 288 for G2 -- cross xGMI in ONE ncclAllGather (elliptic-curve addition is not an RCCL reduction
-// operator, hence gather + add), and every rank adds them on the host.  Latency-bound by construction: world x 144 bytes.
+// One process per GPU.  The `world` ranks form gp point slices x gw window groups (gp * gw = world, chosen per call by
+// msm_dist_split in engine.hip): rank r = p * gw + w computes the windows {k : k mod gw = w} of slice p of the points on its own
+// MI355X (msm_amd_multiexp_shard_async), which leaves ONE Jacobian partial, already weighted by 2^(c*k).  The partials -- 144 bytes
+// for BLS12-381 G1, at most 288 for G2, behind a 16-byte status header -- cross xGMI in ONE ncclAllGather (elliptic-curve addition is
+// not an RCCL reduction operator, hence gather + add), and every rank adds them on the host.  Latency-bound by construction.
+// A rank needs only ITS slice of the bases and scalars in HBM (msm_amd_dist_plan + msm_amd_multiexp_dist_local).
 //
 // RCCL is loaded at run time (dlopen of librccl.so.1): a host that never calls msm_amd_dist_init needs no RCCL at all, and a
 // Python host that has torch loaded shares torch's copy instead of bringing a second one into the process.
@@ -50,6 +53,9 @@ Rccl& rccl() {
     return r;
 }
 constexpr int kNcclUint8 = 1;   // ncclUint8 (rccl.h)
+// what one rank contributes to an exchange: a 16-byte header (word 0: 0 = fine, else the negated error code of a rank whose own part
+// failed) and its Jacobian partial in 288 bytes (the largest, BLS12-381 G2).  The same size for every curve and group.
+constexpr size_t kHeader = 16, kPayload = kHeader + 288;
 
 int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
     msm_set_err(ctx, std::string(what) + ": " + rccl().GetErrorString(rc));
@@ -72,7 +78,7 @@ int msm_amd_dist_unique_id(uint8_t* out128) {
 
 int msm_amd_dist_init(msm_amd_ctx* ctx, int rank, int world, const uint8_t* id128) {
     if (!ctx) return MSM_AMD_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> dl(ctx->dist_mu);   // ctx->dist is guarded by dist_mu
     if (world < 1 || rank < 0 || rank >= world || !id128) {
         msm_set_err(ctx, "dist_init: need 0 <= rank < world and the 128-byte id of rank 0's msm_amd_dist_unique_id");
         return MSM_AMD_EINVAL;
@@ -96,29 +102,39 @@ int msm_amd_dist_init(msm_amd_ctx* ctx, int rank, int world, const uint8_t* id12
                             "(sharded calls in flight may share hardware queues with the sort stream and serialise)\n", world, q ? q : "unset");
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    msm_nccl_id id;
-    memcpy(id.internal, id128, sizeof id.internal);
-    void* comm = nullptr;
-    int rc = r.CommInitRank(&comm, world, id, rank);
-    if (rc != 0) return nccl_fail(ctx, "ncclCommInitRank", rc);
-    ctx->dist.comm = comm;
-    ctx->dist.rank = rank;
-    ctx->dist.world = world;
-    const size_t cap = (size_t)(world + 1) * 288;   // the largest partial is a BLS12-381 G2 Jacobian point
-    hipError_t e = hipMalloc(&ctx->dist.d_buf, cap * msm_amd_ctx::MAX_SLOTS);
-    if (e == hipSuccess) e = hipHostMalloc(&ctx->dist.h_buf, cap * msm_amd_ctx::MAX_SLOTS, hipHostMallocDefault);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->dist.stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-        msm_set_err(ctx, std::string("dist_init: ") + hipGetErrorString(e));
-        return MSM_AMD_EHIP;
+    // staging first, the communicator last, and ctx->dist is only written once everything exists: a failure on the way leaves the
+    // context outside any group (a later dist_init may try again) and leaks nothing
+    msm_amd_ctx::Dist d;
+    d.rank = rank;
+    d.world = world;
+    d.slot_bytes = kPayload;
+    const size_t cap = (size_t)(world + 1) * kPayload;
+    hipError_t e = hipMalloc(&d.d_buf, cap);
+    if (e == hipSuccess) e = hipHostMalloc(&d.h_buf, cap, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking);
+    int nrc = 0;
+    if (e == hipSuccess) {
+        msm_nccl_id id;
+        memcpy(id.internal, id128, sizeof id.internal);
+        nrc = r.CommInitRank(&d.comm, world, id, rank);
     }
-    ctx->dist.slot_bytes = cap;
+    if (e != hipSuccess || nrc != 0) {
+        if (d.stream) (void)hipStreamDestroy(d.stream);
+        if (d.h_buf) (void)hipHostFree(d.h_buf);
+        if (d.d_buf) (void)hipFree(d.d_buf);
+        if (e != hipSuccess) {
+            msm_set_err(ctx, std::string("dist_init: ") + hipGetErrorString(e));
+            return MSM_AMD_EHIP;
+        }
+        return nccl_fail(ctx, "ncclCommInitRank", nrc);
+    }
+    ctx->dist = std::move(d);
     return 0;
 }
 
 int msm_amd_dist_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return MSM_AMD_EINVAL;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> dl(ctx->dist_mu);
     if (!ctx->dist.comm) return 0;
     (void)hipSetDevice(ctx->device);
     if (ctx->dist.stream) {
@@ -129,6 +145,7 @@ int msm_amd_dist_destroy(msm_amd_ctx* ctx) {
     if (ctx->dist.d_buf) (void)hipFree(ctx->dist.d_buf);
     if (ctx->dist.h_buf) (void)hipHostFree(ctx->dist.h_buf);
     ctx->dist = msm_amd_ctx::Dist{};
+    ctx->dist_cv.notify_all();
     return 0;
 }
 
@@ -139,7 +156,56 @@ int msm_amd_dist_info(const msm_amd_ctx* ctx, int* rank, int* world) {
     return 0;
 }
 
-// This rank's windows on this rank's GPU; the ticket is collected with msm_amd_dist_wait.
+// How a call of n points is split over a group of `world` ranks, and which slice of the points rank `rank` takes: gp point slices x
+// gw window groups.  world = 0: this context's own group and rank.
+int msm_amd_dist_plan(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t rank, uint32_t* gp,
+                      uint32_t* gw, uint32_t* first, uint32_t* count) {
+    if (!ctx || !gp || !gw || !first || !count) return MSM_AMD_EINVAL;
+    if (world == 0) {
+        if (!ctx->dist.comm) return MSM_AMD_EINVAL;
+        world = (uint32_t)ctx->dist.world;
+        rank = (uint32_t)ctx->dist.rank;
+    }
+    if (rank >= world || scalar_size < 1 || scalar_size > 64) return MSM_AMD_EINVAL;
+    msm_dist_split(ctx, curve, group, scalar_size, n, world, gp, gw);
+    msm_dist_slice(n, *gp, rank / *gw, first, count);
+    return 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Queue this rank's part -- the windows {k : k % gw == w} of the `count` points behind bases / scalars -- and give it its place in the
+// group's sequence of exchanges.  A part that cannot be queued (bad argument, HIP failure, no free slot) still gets a ticket and a
+// place: the other ranks WILL enter the collective of this call, so this rank has to as well (with a failure mark, see dist_wait).
+int dist_submit(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size, uint32_t count,
+                uint32_t w, uint32_t gw, uint64_t* ticket, int refused_rc = 0, const std::string& refused_why = std::string()) {
+    // (dist_mu is held across the submission so that two threads cannot take sequence numbers in one order and engine tickets in
+    // the other; the submission itself only queues GPU work)
+    std::lock_guard<std::mutex> dl(ctx->dist_mu);
+    msm_amd_ctx::Dist::Rec rec;
+    rec.curve = curve;
+    rec.group = group;
+    if (refused_rc) {   // the entry point has already found the call unusable on this rank
+        rec.rc = refused_rc;
+        rec.err = refused_why;
+    } else {
+        rec.rc = msm_amd_multiexp_shard_async(ctx, curve, group, flags, bases, scalars, scalar_size, count, w, gw, &rec.engine_ticket);
+        if (rec.rc) rec.err = msm_amd_last_error(ctx);
+    }
+    rec.seq = ctx->dist.next_seq++;
+    const uint64_t id = ctx->dist.next_id++;
+    ctx->dist.recs[id] = rec;
+    *ticket = id;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Every rank holds ALL n points and scalars; this rank works on its slice and windows of them.
 int msm_amd_multiexp_dist_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
                                 uint32_t n, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
@@ -147,44 +213,149 @@ int msm_amd_multiexp_dist_async(msm_amd_ctx* ctx, int curve, int group, uint32_t
         msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
         return MSM_AMD_EINVAL;
     }
-    return msm_amd_multiexp_shard_async(ctx, curve, group, flags, bases, scalars, scalar_size, n, (uint32_t)ctx->dist.rank, (uint32_t)ctx->dist.world,
-                                        ticket);
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || scalar_size < 1 || scalar_size > 64) {
+        msm_set_err(ctx, "multiexp_dist: bad curve / group / scalar_size");
+        return MSM_AMD_EINVAL;   // (the same on every rank: nothing was queued anywhere)
+    }
+    uint32_t gp, gw, first, count;
+    msm_dist_split(ctx, curve, group, scalar_size, n, (uint32_t)ctx->dist.world, &gp, &gw);
+    msm_dist_slice(n, gp, (uint32_t)ctx->dist.rank / gw, &first, &count);
+    const size_t bstride = (size_t)((flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group;
+    const uint8_t* b = bases ? (const uint8_t*)bases + (size_t)first * bstride : nullptr;
+    const uint8_t* s = scalars ? (const uint8_t*)scalars + (size_t)first * scalar_size : nullptr;
+    return dist_submit(ctx, curve, group, flags, b, s, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket);
 }
 
-// Waits for this rank's partial, exchanges the partials of all ranks (one ncclAllGather of world x jacobian bytes) and writes the
-// normalised sum -- the same bytes on every rank.  Every rank must wait for its tickets in the same order.
+// This rank holds only ITS slice of the n_total points (msm_amd_dist_plan says which): bases_local / scalars_local are that slice.
+int msm_amd_multiexp_dist_local_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases_local, const void* scalars_local,
+                                      uint32_t scalar_size, uint32_t n_local, uint32_t n_total, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    if (!ctx->dist.comm) {
+        msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
+        return MSM_AMD_EINVAL;
+    }
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || scalar_size < 1 || scalar_size > 64) {
+        msm_set_err(ctx, "multiexp_dist: bad curve / group / scalar_size");
+        return MSM_AMD_EINVAL;
+    }
+    uint32_t gp, gw, first, count;
+    msm_dist_split(ctx, curve, group, scalar_size, n_total, (uint32_t)ctx->dist.world, &gp, &gw);
+    msm_dist_slice(n_total, gp, (uint32_t)ctx->dist.rank / gw, &first, &count);
+    if (n_local != count) {
+        // the caller's buffers hold n_local points; reading `count` of them would run past their end (or drop points).  The split
+        // depends on the context's options: plan and call must see the same ones.  Symmetric across ranks only if the caller's mistake
+        // is -- so this rank still takes part in the exchange, with a failure mark.
+        const std::string why = "multiexp_dist_local: n_local = " + std::to_string(n_local) + " but this rank's slice of " + std::to_string(n_total) +
+                                " points is " + std::to_string(count) + " (msm_amd_dist_plan; were options changed in between?)";
+        return dist_submit(ctx, curve, group, flags, nullptr, nullptr, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket, MSM_AMD_EINVAL, why);
+    }
+    return dist_submit(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket);
+}
+
+// Waits for this rank's partial, takes part in the exchange of this call (one ncclAllGather of world x 304 bytes: a status word and
+// the Jacobian partial of every rank) and writes the normalised sum -- the same bytes on every rank.
+// The exchanges of a context happen in the order in which its calls were SUBMITTED, whatever the order (and the threads) in which they
+// are waited for: every rank submits the same calls in the same order, so the collectives match -- two promises resolved by two
+// libuv workers cannot cross, and a G1 call cannot meet a G2 call.  Every ticket must be waited for (a later one waits its turn).
+// A rank whose own part failed still takes part, with a failure mark: it returns its error, the others MSM_AMD_EPEER.
 int msm_amd_dist_wait(msm_amd_ctx* ctx, int curve, int group, uint64_t ticket, uint8_t* out) {
     if (!ctx || !out) return MSM_AMD_EINVAL;
-    if (!ctx->dist.comm) {
-        msm_set_err(ctx, "dist_wait: msm_amd_dist_init first");
-        return MSM_AMD_EINVAL;
-    }
-    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2)) {
-        msm_set_err(ctx, "unknown curve/group");
-        return MSM_AMD_EINVAL;
+    msm_amd_ctx::Dist::Rec rec;
+    {
+        std::lock_guard<std::mutex> dl(ctx->dist_mu);
+        if (!ctx->dist.comm) {
+            msm_set_err(ctx, "dist_wait: msm_amd_dist_init first");
+            return MSM_AMD_EINVAL;
+        }
+        auto it = ctx->dist.recs.find(ticket);
+        if (it == ctx->dist.recs.end() || it->second.waiting) {
+            msm_set_err(ctx, "dist_wait: unknown or already collected ticket");
+            return MSM_AMD_EINVAL;
+        }
+        if (it->second.curve != curve || it->second.group != group) {
+            msm_set_err(ctx, "dist_wait: curve / group differ from the call that issued the ticket");
+            return MSM_AMD_EINVAL;
+        }
+        it->second.waiting = true;
+        rec = it->second;
     }
     const size_t jsz = (size_t)3 * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group;
-    uint8_t mine[288];
-    if (int rc = msm_amd_wait(ctx, ticket, mine)) return rc;
-    // the exchanges of one context are serialised (collectives of one communicator must be issued in the same order on every rank)
-    std::lock_guard<std::mutex> lk(ctx->dist_mu);
-    HIPCHK(ctx, hipSetDevice(ctx->device));
+    uint8_t mine[kPayload] = {};
+    int rc_local = rec.rc;
+    std::string err_local = rec.err;
+    if (rc_local == 0) {
+        rc_local = msm_amd_wait(ctx, rec.engine_ticket, mine + kHeader);   // outside dist_mu: other calls are submitted and waited for meanwhile
+        if (rc_local) err_local = msm_amd_last_error(ctx);
+    }
+    if (rc_local) {   // the point at infinity and the mark
+        memset(mine, 0, sizeof mine);
+        const uint32_t mark = (uint32_t)(-rc_local);
+        memcpy(mine, &mark, 4);
+    }
+    std::unique_lock<std::mutex> dl(ctx->dist_mu);
+    ctx->dist_cv.wait(dl, [&] { return !ctx->dist.comm || ctx->dist.next_exchange == rec.seq; });
+    if (!ctx->dist.comm) {
+        msm_set_err(ctx, "dist_wait: the group was destroyed while a call was waiting for its exchange");
+        return MSM_AMD_EINVAL;
+    }
+    int rc = 0;
     const int world = ctx->dist.world;
     uint8_t* d = (uint8_t*)ctx->dist.d_buf;
     uint8_t* h = (uint8_t*)ctx->dist.h_buf;
-    memcpy(h, mine, jsz);
-    HIPCHK(ctx, hipMemcpyAsync(d, h, jsz, hipMemcpyHostToDevice, ctx->dist.stream));
-    int rc = rccl().AllGather(d, d + 288, jsz, kNcclUint8, ctx->dist.comm, ctx->dist.stream);
-    if (rc != 0) return nccl_fail(ctx, "ncclAllGather", rc);
-    HIPCHK(ctx, hipMemcpyAsync(h + 288, d + 288, jsz * (size_t)world, hipMemcpyDeviceToHost, ctx->dist.stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->dist.stream));
-    return msm_amd_combine(curve, group, h + 288, (uint32_t)world, out);
+    do {
+        if (hipSetDevice(ctx->device) != hipSuccess) { rc = MSM_AMD_EHIP; msm_set_err(ctx, "dist_wait: hipSetDevice failed"); break; }
+        memcpy(h, mine, kPayload);
+        hipError_t e = hipMemcpyAsync(d, h, kPayload, hipMemcpyHostToDevice, ctx->dist.stream);
+        int nrc = 0;
+        if (e == hipSuccess) nrc = rccl().AllGather(d, d + kPayload, kPayload, kNcclUint8, ctx->dist.comm, ctx->dist.stream);
+        if (e == hipSuccess && nrc == 0) e = hipMemcpyAsync(h + kPayload, d + kPayload, kPayload * (size_t)world, hipMemcpyDeviceToHost, ctx->dist.stream);
+        const hipError_t e2 = hipStreamSynchronize(ctx->dist.stream);
+        if (nrc != 0) { rc = nccl_fail(ctx, "ncclAllGather", nrc); break; }
+        if (e != hipSuccess || e2 != hipSuccess) {
+            rc = MSM_AMD_EHIP;
+            msm_set_err(ctx, std::string("dist_wait: ") + hipGetErrorString(e != hipSuccess ? e : e2));
+            break;
+        }
+    } while (0);
+    // this call's turn is over whatever happened: the next one may go
+    ++ctx->dist.next_exchange;
+    ctx->dist.recs.erase(ticket);
+    std::vector<uint8_t> parts;
+    int failed_rank = -1;
+    if (rc == 0) {
+        parts.resize((size_t)world * jsz);
+        for (int k = 0; k < world; ++k) {
+            uint32_t mark;
+            memcpy(&mark, h + kPayload * (size_t)(k + 1), 4);
+            if (mark && failed_rank < 0) failed_rank = k;
+            memcpy(parts.data() + (size_t)k * jsz, h + kPayload * (size_t)(k + 1) + kHeader, jsz);
+        }
+    }
+    dl.unlock();
+    ctx->dist_cv.notify_all();
+    if (rc) return rc;
+    if (rc_local) {
+        msm_set_err(ctx, err_local);
+        return rc_local;
+    }
+    if (failed_rank >= 0) {
+        msm_set_err(ctx, "multiexp_dist: rank " + std::to_string(failed_rank) + " of the group failed its part of this call (its own error text says why)");
+        return MSM_AMD_EPEER;
+    }
+    return msm_amd_combine(curve, group, parts.data(), (uint32_t)world, out);
 }
 
 int msm_amd_multiexp_dist(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
                           uint32_t n, uint8_t* out) {
     uint64_t t = 0;
     if (int rc = msm_amd_multiexp_dist_async(ctx, curve, group, flags, bases, scalars, scalar_size, n, &t)) return rc;
+    return msm_amd_dist_wait(ctx, curve, group, t, out);
+}
+
+int msm_amd_multiexp_dist_local(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases_local, const void* scalars_local,
+                                uint32_t scalar_size, uint32_t n_local, uint32_t n_total, uint8_t* out) {
+    uint64_t t = 0;
+    if (int rc = msm_amd_multiexp_dist_local_async(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, n_local, n_total, &t)) return rc;
     return msm_amd_dist_wait(ctx, curve, group, t, out);
 }
 

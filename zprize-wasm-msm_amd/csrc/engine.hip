@@ -116,6 +116,52 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
     return c;
 }
 
+// How a call of a multi-GPU group is split: gp point slices x gw window groups, gp * gw = world.  Both seams are the reference's own
+// (per-window fnName_chunk, build_multiexp.js:96-104; the full call as a sum over point slices, :251-371, which is what its external
+// caller does above 2^22 points).  Cutting the points keeps every rank's bucket count and halves the bucket populations; cutting the
+// windows keeps the populations and divides the buckets -- and with them the latency-bound reduction, which is what a small call
+// consists of.  The estimate below is the per-rank cost model fitted to the measurements of tools/bench_shard.py (one rank's share run
+// alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
+static double shard_cost_ms(const msm_amd_ctx* ctx, uint32_t n_slice, uint32_t nbits, uint32_t gw, bool g1, double add_ns) {
+    if (n_slice == 0) return 0.0;
+    const uint32_t c = pick_window_bits(n_slice, nbits, ctx->force_c, gw, ctx->no_split2 ? 4096u : (g1 ? 98304u : 65537u));
+    const uint32_t W = nbits / c + 1, own = (W + gw - 1) / gw;
+    const double half = (double)(1u << (c - 1)), nb_own = own * half, adds = (double)own * n_slice;
+    // accumulation: launches short of ~5 waves per SIMD (327680 buckets) run sliced, with a join, at ~85 % of the full rate
+    const double acc = adds * add_ns * (nb_own >= 327680.0 ? 1.0 : 1.0 / 0.85) * 1e-6;
+    // reduction: two full additions per bucket at about half the accumulation's rate, and never less than its dependent chain
+    const double red = std::max(0.30, nb_own * 2.0 * add_ns * 2.2 * 1e-6);
+    // sort: ~0.12 ms of launches, then ~10 us per million (pair, window) entries
+    const double sort = 0.12 + adds * 1.0e-8;
+    return sort + acc + red;
+}
+void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw) {
+    *gp = 1;
+    *gw = world ? world : 1;
+    if (world <= 1) return;
+    if (ctx->dist_gw && world % ctx->dist_gw == 0) {
+        *gw = ctx->dist_gw;
+        *gp = world / ctx->dist_gw;
+        return;
+    }
+    const uint32_t nbits = scalar_size * 8;
+    // ns per bucket addition of the accumulation kernels on one MI355X (BLS12-381 G1: 6.9-8.1 G additions per second)
+    const double add_ns = (curve == MSM_AMD_BLS12381 ? 0.140 : 0.066) * (group == 2 ? 3.2 : 1.0);
+    double best = 1e300;
+    for (uint32_t w = 1; w <= world; ++w) {
+        if (world % w) continue;
+        const uint32_t p = world / w;
+        const uint32_t n_slice = (uint32_t)(((uint64_t)n + p - 1) / p);
+        if (p > 1 && n_slice < 4096) continue;   // slices this small are all fixed cost
+        const double t = shard_cost_ms(ctx, n_slice, nbits, w, group == 1, add_ns);
+        if (t < best * 0.97 || (t < best && w > *gw)) {   // (near-ties go to the split found first: fewer window groups, i.e. smaller inputs per rank)
+            best = t;
+            *gw = w;
+            *gp = p;
+        }
+    }
+}
+
 struct RunArgs {
     const void* bases;
     const void* scalars;
@@ -308,13 +354,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
         if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * (e32 ? 4 : 8))) return rc;
-        {
-            // a buffer that grows is freed and allocated anew -- possibly at the SAME address, so "known to be zero" must not be keyed
-            // on the pointer alone: the bytes beyond the old capacity are whatever the allocator hands out
-            const size_t cap_before = sl->d_binhist.cap;
-            if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
-            if (sl->d_binhist.cap != cap_before) sl->binhist_zero = nullptr;
-        }
+        // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
+        // well, ZeroMark in engine_ctx.hpp)
+        if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_binstart, ((size_t)sg.nbins + 1) * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_bincur, (size_t)sg.nbins * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
@@ -344,8 +386,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             return MSM_AMD_EINVAL;
         }
         // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
-        if (sl->binhist_zero != sl->d_binhist.p) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
-        sl->binhist_zero = nullptr;   // until this submission has got as far as k_bin_scan
+        if (!sl->binhist_zero.holds(sl->d_binhist)) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
+        sl->binhist_zero.clear();   // until this submission has got as far as k_bin_scan
 #define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist)
         if (wide) {
             if (nw == 8) MSM_TILE_HIST(8, 1024);
@@ -360,7 +402,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. bin starts
         k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
-        sl->binhist_zero = sl->d_binhist.p;
+        sl->binhist_zero.set(sl->d_binhist);
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
         // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
@@ -748,7 +790,7 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return MSM_AMD_EINVAL;
     }
     if (rc) {
-        sl->binhist_zero = nullptr;   // whatever the sort had counted so far is not to be trusted
+        sl->binhist_zero.clear();   // whatever the sort had counted so far is not to be trusted
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream_s);
         if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);
@@ -1076,6 +1118,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
     if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size
     if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A
     if (!strcmp(name, "acc_variant")) { ctx->acc_variant = value; return 0; }   // experiments: 1 = two-chain build, 2 = chained build, 0 = by launch size

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <map>
 #include <atomic>
 #include <mutex>
 #include <cstdio>
@@ -21,9 +22,31 @@
 #include "glv.hpp"
 
 namespace msm {
+// A scratch buffer in HBM that grows on demand (ensure()).  `gen` counts its allocations: whatever the engine remembers ABOUT THE
+// CONTENTS of a buffer ("all zero since the last call") is keyed on (pointer, generation), never on the pointer alone -- a buffer
+// that grows is freed and allocated anew, and the allocator may hand the same address back with the larger size (round 2: the sort's
+// bin histogram was then taken for still-zero beyond its old capacity, one GPU memory fault).
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
+    uint64_t gen = 0;   // 0 = never allocated
+};
+// what ensure() allocates with; a host-only test swaps in an allocator that returns the same address again (tests/host/test_devbuf.hip)
+struct DevAllocHooks {
+    hipError_t (*alloc)(void**, size_t) = [](void** p, size_t n) { return hipMalloc(p, n); };
+    hipError_t (*release)(void*) = [](void* p) { return hipFree(p); };
+};
+inline DevAllocHooks& dev_alloc_hooks() {
+    static DevAllocHooks h;
+    return h;
+}
+// "this buffer has held nothing but zeros since allocation `gen`" -- a mark taken with mark_zero() and tested with is_zero()
+struct ZeroMark {
+    const void* p = nullptr;
+    uint64_t gen = 0;
+    void set(const DevBuf& b) { p = b.p; gen = b.gen; }
+    void clear() { p = nullptr; gen = 0; }
+    bool holds(const DevBuf& b) const { return b.p != nullptr && p == b.p && gen == b.gen; }
 };
 
 }  // namespace msm
@@ -37,7 +60,7 @@ struct Slot {
     DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout, d_slices;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
-    const void* binhist_zero = nullptr;   // == d_binhist.p while that buffer is known to be all zero (sort: k_bin_scan leaves it so)
+    ZeroMark binhist_zero;        // holds(d_binhist) while that buffer is known to be all zero (sort: k_bin_scan leaves it so)
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts
@@ -67,6 +90,7 @@ struct msm_nccl_id {   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by valu
 struct msm_amd_ctx {
     int device = 0;
     // multi-GPU group this context belongs to (dist.hip): RCCL communicator + staging for the exchange of the window partials
+    // (guarded by dist_mu)
     struct Dist {
         void* comm = nullptr;
         int rank = 0, world = 0;
@@ -74,8 +98,21 @@ struct msm_amd_ctx {
         void* h_buf = nullptr;   // pinned
         hipStream_t stream = nullptr;
         size_t slot_bytes = 0;
+        // One record per call of the group that this rank has submitted and not yet exchanged.  The exchanges (collectives of one
+        // communicator) happen in submission order -- `seq` -- on every rank, whichever thread waits for which ticket when.
+        struct Rec {
+            uint64_t seq = 0, engine_ticket = 0;
+            int curve = 0, group = 0;
+            int rc = 0;          // != 0: this rank's part could not even be queued; it still takes part in the exchange, with a failure mark
+            std::string err;
+            bool waiting = false;
+        };
+        std::map<uint64_t, Rec> recs;   // by dist ticket
+        uint64_t next_id = 1, next_seq = 0, next_exchange = 0;
     } dist;
-    std::mutex dist_mu;   // collectives of one communicator are issued one at a time
+    std::mutex dist_mu;
+    std::condition_variable dist_cv;   // next_exchange moved on
+    uint32_t dist_gw = 0;              // option "dist_gw": window groups of a sharded call (0 = chosen per call; must divide the world size)
     // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are
     // serialised by `mu`; WAITING for the GPU happens outside it, so calls issued from different threads -- e.g. the libuv
     // workers behind two unresolved JS promises -- overlap on the GPU like explicitly pipelined ones.  A synchronous call that
@@ -112,6 +149,15 @@ struct msm_amd_ctx {
 // so it is guarded by its own small lock, and msm_amd_last_error hands out a per-thread copy.
 void msm_set_err(msm_amd_ctx* ctx, const std::string& msg);
 
+// The split of a call of n points over `world` ranks (engine.hip): gp point slices x gw window groups, gp * gw = world.
+void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw);
+// Slice p of gp: points [first, first + count) -- equal slices of ceil(n / gp), the last ones shorter or empty.
+inline void msm_dist_slice(uint32_t n, uint32_t gp, uint32_t p, uint32_t* first, uint32_t* count) {
+    const uint64_t per = ((uint64_t)n + gp - 1) / gp, lo = std::min<uint64_t>((uint64_t)p * per, n), hi = std::min<uint64_t>(lo + per, n);
+    *first = (uint32_t)lo;
+    *count = (uint32_t)(hi - lo);
+}
+
 #define HIPCHK(ctx, call)                                                                                      \
     do {                                                                                                       \
         hipError_t e_ = (call);                                                                                \
@@ -123,12 +169,13 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg);
 
 inline int ensure(msm_amd_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.cap >= bytes && b.p) return 0;
-    if (b.p) HIPCHK(ctx, hipFree(b.p));
+    if (b.p) HIPCHK(ctx, dev_alloc_hooks().release(b.p));
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 8 + 256;
-    HIPCHK(ctx, hipMalloc(&b.p, want));
+    HIPCHK(ctx, dev_alloc_hooks().alloc(&b.p, want));
     b.cap = want;
+    ++b.gen;   // a new allocation: nothing known about its contents, whatever its address
     return 0;
 }
 

@@ -298,8 +298,11 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
     ds.load(scalars, g, tile * T);
     const uint32_t ncnt = GW * sg.cb;
     for (uint32_t w0 = 0; w0 < g.W; w0 += GW) {
-        uint32_t mr[GW][ITEMS];   // magnitude (<= 2^20) << 12 | rank inside the run
-        uint32_t negm[GW];
+        // (bucket index = magnitude - 1, < 2^20) << 12 | rank inside the run (< 4096).  Validity is kept apart (livem): with the
+        // magnitude itself packed, a digit of exactly 2^20 (c = 21) shifted out of the word -- the entry was dropped or indexed LDS
+        // out of bounds -- and every value of the packed word is a legitimate (bucket, rank) pair, so none is free as a marker.
+        uint32_t mr[GW][ITEMS];
+        uint32_t negm[GW], livem[GW];
         bool any = false;
         for (uint32_t s = t; s < ncnt; s += BLOCK) hs[s] = 0;
         __syncthreads();
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
             const uint32_t w = w0 + gw;
             const bool owned = w < g.W && (w % g.nshards) == g.shard;
             any |= owned;
-            negm[gw] = 0;
+            negm[gw] = livem[gw] = 0;
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 mr[gw][k] = 0;
@@ -317,7 +320,10 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
                     bool neg;
                     ds.next(scalars, g, k, w, mag, neg);
                     if (neg) negm[gw] |= 1u << k;
-                    if (owned && mag != 0) mr[gw][k] = (mag << 12) | atomicAdd(&hs[gw * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
+                    if (owned && mag != 0) {
+                        livem[gw] |= 1u << k;
+                        mr[gw][k] = ((mag - 1) << 12) | atomicAdd(&hs[gw * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
+                    }
                 }
             }
         }
@@ -333,8 +339,8 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
         for (int gw = 0; gw < GW; ++gw) {
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
-                if (mr[gw][k] != 0) {
-                    const uint32_t b = (mr[gw][k] >> 12) - 1, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
+                if ((livem[gw] >> k) & 1u) {
+                    const uint32_t b = mr[gw][k] >> 12, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
                     stage[slot] = make_entry<E>(ds.first + k * BLOCK, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
                     srun[slot] = (uint16_t)run;
                 }

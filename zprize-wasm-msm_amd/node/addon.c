@@ -51,6 +51,8 @@ static int (*p_dist_id)(uint8_t *);
 static int (*p_dist_init)(msm_amd_ctx *, int, int, const uint8_t *);
 static int (*p_dist_destroy)(msm_amd_ctx *);
 static int (*p_multiexp_dist)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint8_t *);
+static int (*p_multiexp_dist_async)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint64_t *);
+static int (*p_dist_wait)(msm_amd_ctx *, int, int, uint64_t, uint8_t *);
 
 static const char *load_engine(void) {
     if (g_lib) return NULL;
@@ -103,6 +105,8 @@ static const char *load_engine(void) {
     SYM(p_dist_init, "msm_amd_dist_init")
     SYM(p_dist_destroy, "msm_amd_dist_destroy")
     SYM(p_multiexp_dist, "msm_amd_multiexp_dist")
+    SYM(p_multiexp_dist_async, "msm_amd_multiexp_dist_async")
+    SYM(p_dist_wait, "msm_amd_dist_wait")
 #undef SYM
     return NULL;
 }
@@ -202,6 +206,7 @@ typedef struct {
     int rc;
     char err[256];
     /* async only */
+    uint64_t dist_ticket; /* is_chunk == 3: submitted on the JS thread, only the wait runs on the worker */
     napi_async_work work;
     napi_deferred deferred;
     napi_ref ref_bases, ref_scalars;
@@ -243,7 +248,9 @@ static int parse_call(napi_env env, napi_callback_info info, call_t *c, int is_c
     return 0;
 }
 static void run_call(call_t *c) {
-    if (c->is_chunk == 2)
+    if (c->is_chunk == 3)
+        c->rc = p_dist_wait(c->ctx, c->curve, c->group, c->dist_ticket, c->out);
+    else if (c->is_chunk == 2)
         c->rc = p_multiexp_dist(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->out);
     else if (c->is_chunk)
         c->rc = p_multiexp_chunk(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, c->start_bit, c->chunk_size, c->out);
@@ -305,6 +312,21 @@ static napi_value js_multiexp_async_common(napi_env env, napi_callback_info info
     if (parse_call(env, info, c, is_chunk)) {
         free(c);
         return NULL;
+    }
+    if (is_chunk == 2) {
+        /* A call of a multi-GPU group is SUBMITTED here, on the JS thread, in the order of the JS calls -- the same order on every
+         * rank, which is the order the group's exchanges then take (msm_amd_dist_wait).  Submitted from the libuv workers instead,
+         * two promises in flight (two slices of one multiExp, or a G1 and a G2 call of a prover) would reach the engine in an order
+         * that depends on thread timing and differs between ranks.  Only the wait runs on the worker. */
+        int rc = p_multiexp_dist_async(c->ctx, c->curve, c->group, c->flags, c->bases, c->scalars, c->scalar_size, c->n, &c->dist_ticket);
+        if (rc) {
+            char msg[320];
+            snprintf(msg, sizeof msg, "libmsm_amd error %d: %s", rc, p_last_error(c->ctx));
+            free(c);
+            napi_throw_error(env, "MSM_AMD_ERROR", msg);
+            return NULL;
+        }
+        c->is_chunk = 3;
     }
     size_t argc = 10;
     napi_value argv[10], promise, name;

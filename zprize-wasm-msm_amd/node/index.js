@@ -125,6 +125,18 @@ function curve(curveName, opts) {
     const maxSlice = (opts && opts.maxSlice) || (1 << 22);
     const dist = opts && opts.dist;
     if (dist) native.distInit(ctx, dist.rank, dist.world, dist.id);
+    const distQueue = [];
+    let distInFlight = 0;
+    const distPump = () => {
+        while (distInFlight < 2 && distQueue.length) {
+            const q = distQueue.shift();
+            distInFlight++;
+            let p;
+            try { p = native.multiexpDistAsync(...q.args); } catch (e) { p = Promise.reject(e); }
+            p.then(q.resolve, q.reject).then(() => { distInFlight--; distPump(); });
+        }
+    };
+    const distCall = (...args) => new Promise((resolve, reject) => { distQueue.push({ args, resolve, reject }); distPump(); });
     const group = (g) => {
         const fsz = C.n8 * g;
         // ffjavascript's G.multiExp[Affine] (package ffjavascript@0.2.56, NOT in the reference tree: behaviour modelled from upstream
@@ -132,7 +144,11 @@ function curve(curveName, opts) {
         // into slices of at most 2^22, every slice is one multi-exponentiation (there: one `_chunk` task per window on a worker pool,
         // Horner on the main thread; here: one engine call, windows and Horner inside it) and the slice results are added.
         // opts.dist = {rank, world, id}: this process is one rank of a multi-GPU group (msm_amd_dist_*; every rank makes the same calls).
-        const call = dist ? native.multiexpDistAsync : native.multiexpAsync;
+        // A call of a group is submitted to the engine inside native.multiexpDistAsync, on this (the JS) thread, so the order of the
+        // group's exchanges is the order of the JS calls -- the same on every rank.  `distCall` keeps at most two of them submitted
+        // (the engine's slots) and the rest in a FIFO: concurrent promises -- slices of one multiExp, a G1 and a G2 call of a
+        // prover -- are queued, never reordered and never refused for want of a slot.
+        const call = dist ? distCall : native.multiexpAsync;
         const run = (flags, stride) => async function (buffBases, buffScalars) {
             const n = Math.floor(buffBases.byteLength / stride);
             if (n * stride !== buffBases.byteLength) throw new RangeError("bases length is not a whole number of points");

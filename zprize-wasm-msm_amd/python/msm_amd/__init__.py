@@ -32,7 +32,14 @@ FLAG_BASES_IN_SUBGROUP = 16
 
 
 class MsmAmdError(RuntimeError):
-    pass
+    """code: the library's MSM_AMD_E* value when the error came from it (EINVAL -1, EHIP -2, ENOMEM -3, EPEER -4)"""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+EINVAL, EHIP, ENOMEM, EPEER = -1, -2, -3, -4
 
 
 _lib = None
@@ -80,6 +87,9 @@ def load_library(path=None):
     L.msm_amd_multiexp_dist.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
     L.msm_amd_multiexp_dist_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_dist_wait.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u8p]
+    L.msm_amd_dist_plan.argtypes = [vp, c.c_int, c.c_int, u32, u32, u32, u32] + [c.POINTER(u32)] * 4
+    L.msm_amd_multiexp_dist_local.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u8p]
+    L.msm_amd_multiexp_dist_local_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_normalize.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_to_affine.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
@@ -109,6 +119,7 @@ def load_library(path=None):
     L.msm_amd_h2d.argtypes = [vp, vp, vp, c.c_size_t]
     L.msm_amd_d2h.argtypes = [vp, vp, vp, c.c_size_t]
     L.msm_amd_gen_points.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u32, vp]
+    L.msm_amd_gen_points_range.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u32, u32, vp]
     L.msm_amd_get_timings.argtypes = [vp, c.POINTER(c.c_float), c.c_int]
     L.msm_amd_get_geometry.argtypes = [vp, c.POINTER(u32)]
     _lib = L
@@ -140,6 +151,21 @@ class DeviceBuffer:
         if self.ptr:
             self.eng.L.msm_amd_dev_free(self.eng.ctx, self.ptr)
             self.ptr = None
+
+    def view(self, offset, nbytes=None):
+        """The bytes [offset, offset + nbytes) of this buffer as a device pointer of their own (no ownership): a slice of resident
+        bases or scalars handed to a call."""
+        return DeviceView(self, offset, self.nbytes - offset if nbytes is None else nbytes)
+
+
+class DeviceView(DeviceBuffer):
+    def __init__(self, parent, offset, nbytes):
+        assert 0 <= offset and offset + nbytes <= parent.nbytes
+        self.eng, self.nbytes, self.parent = parent.eng, nbytes, parent
+        self.ptr = parent.ptr + offset
+
+    def free(self):
+        self.ptr = None
 
 
 def _as_ptr(x):
@@ -183,7 +209,7 @@ class Engine:
 
     def _chk(self, rc):
         if rc != 0:
-            raise MsmAmdError(f"libmsm_amd error {rc}: {self.L.msm_amd_last_error(self.ctx).decode()}")
+            raise MsmAmdError(f"libmsm_amd error {rc}: {self.L.msm_amd_last_error(self.ctx).decode()}", rc)
 
     def curve(self, name):
         return Curve(self, name)
@@ -204,6 +230,16 @@ class Engine:
 
     def dist_destroy(self):
         self._chk(self.L.msm_amd_dist_destroy(self.ctx))
+
+    def dist_plan(self, curve, group, scalar_size, n, world=0, rank=0):
+        """msm_amd_dist_plan: how a call of n points is split over a group of `world` ranks (0: this engine's own group and rank) --
+        {gp, gw, first, count}: gp point slices x gw window groups; [first, first + count) is the slice of the points that rank
+        `rank` = p * gw + w works on."""
+        v = [ctypes.c_uint32() for _ in range(4)]
+        rc = self.L.msm_amd_dist_plan(self.ctx, CURVES[curve], group, scalar_size, n, world, rank, *[ctypes.byref(x) for x in v])
+        if rc:
+            raise MsmAmdError(f"msm_amd_dist_plan failed ({rc}): not in a group, or bad world / rank / scalar_size", rc)
+        return dict(zip(("gp", "gw", "first", "count"), (x.value for x in v)))
 
     def timings(self):
         arr = (ctypes.c_float * 8)()
@@ -354,6 +390,19 @@ class Curve:
         self.eng._chk(self.eng.L.msm_amd_multiexp_dist_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n, ctypes.byref(t)))
         return DistTicket(self, group, t.value, (kb, ks))
 
+    def multiexp_dist_local(self, group, bases_local, scalars_local, scalar_size, n_local, n_total, jacobian_bases=False):
+        """msm_amd_multiexp_dist_local: like multiexp_dist for a rank that holds only its slice -- n_local points -- of the n_total
+        points (Engine.dist_plan says which)."""
+        return self.multiexp_dist_local_async(group, bases_local, scalars_local, scalar_size, n_local, n_total, jacobian_bases).wait()
+
+    def multiexp_dist_local_async(self, group, bases_local, scalars_local, scalar_size, n_local, n_total, jacobian_bases=False):
+        pb, dev_b, kb = _as_ptr(bases_local)
+        ps, dev_s, ks = _as_ptr(scalars_local)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | self._residency_flags(dev_b, dev_s)
+        t = ctypes.c_uint64()
+        self.eng._chk(self.eng.L.msm_amd_multiexp_dist_local_async(self.eng.ctx, self.cid, group, flags, pb, ps, scalar_size, n_local, n_total, ctypes.byref(t)))
+        return DistTicket(self, group, t.value, (kb, ks))
+
     # --- batch conversions either side of the MSM (the reference's g?m_batch* exports), host buffers ---------
     def _conv(self, fn, group, data, in_sz, out_sz):
         data = bytes(data)
@@ -486,9 +535,10 @@ class Curve:
         self.eng._chk(self.eng.L.msm_amd_glv_preprocess(self.eng.ctx, 0, pp, ps, n, po, so))
         return po.raw, so.raw
 
-    def gen_points(self, group, seed, n):
+    def gen_points(self, group, seed, n, first=0):
+        """n synthetic affine points k_i * G, i = first .. first + n - 1 of the sequence of `seed`, in a new device buffer"""
         buf = self.eng.alloc(max(16, n * self.affine_bytes(group)))
-        self.eng._chk(self.eng.L.msm_amd_gen_points(self.eng.ctx, self.cid, group, seed, n, buf.ptr))
+        self.eng._chk(self.eng.L.msm_amd_gen_points_range(self.eng.ctx, self.cid, group, seed, first, n, buf.ptr))
         return buf
 
 
