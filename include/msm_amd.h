@@ -43,6 +43,7 @@ extern "C" {
 #endif
 
 typedef struct msm_amd_ctx msm_amd_ctx;
+typedef struct msm_amd_bases msm_amd_bases; /* prepared bases (msm_amd_prepare_bases) */
 
 enum { MSM_AMD_BLS12381 = 0, MSM_AMD_BN128 = 1 };
 
@@ -110,6 +111,32 @@ int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
 int msm_amd_multiexp_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
                            const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);
 int msm_amd_wait(msm_amd_ctx *ctx, uint64_t ticket, uint8_t *out);
+
+/* ---- prepared bases: the fixed points of a prover (its SRS), set up once ------------------------------------------------------
+ * The reference is called with the same bases over and over (wasmcurves/benchmarks/multiexp.js:18-41; a Groth16 / PLONK prover's
+ * SRS); what it recomputes per call that depends on the bases alone can be kept.  msm_amd_prepare_bases builds, on the GPU, the
+ * table 2^(start bit of window w) * P_i for every window w (W x n affine points in HBM: 1.25 GB for n = 2^20 BLS12-381 G1 points,
+ * 13 windows).  A call on the handle then sorts the digit of EVERY window of every scalar into ONE bucket set -- entry (i, w)
+ * addresses table point w * n + i -- so buckets, bucket reduction and the window combine shrink from W windows' worth to one, and
+ * the windows can be wider: n = 2^20 runs 13 windows over 2^19 buckets, 13 instead of 16 bucket additions per pair.
+ * Same result bytes as msm_amd_multiexp on the same points (the normalised Jacobian point).
+ *   scalar_bits  the table serves scalars below 2^scalar_bits; 0 = the bit length of the curve's group order (255 / 254: any scalar
+ *                reduced mod r).  A call that meets a wider scalar fails with MSM_AMD_EINVAL -- nothing is truncated silently.
+ *   flags        msm_amd_prepare_bases: MSM_AMD_BASES_JACOBIAN, MSM_AMD_DEVICE_PTRS (bases resident on this GPU);
+ *                msm_amd_multiexp_prepared: MSM_AMD_DEVICE_PTRS (scalars resident).
+ *   n            a call may use any prefix of the prepared points.
+ * The asynchronous form returns a ticket for msm_amd_wait.  A handle is released with msm_amd_release_bases once no call on it is
+ * in flight; it belongs to the context that prepared it.  Option "window_bits" (>= 3) at prepare time forces the table's window size. */
+int msm_amd_prepare_bases(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, uint32_t n,
+                          uint32_t scalar_bits, msm_amd_bases **out);
+int msm_amd_release_bases(msm_amd_ctx *ctx, msm_amd_bases *bases);
+/* out6: [0] points, [1] scalar_bits, [2] c, [3] windows W, [4] signed windows (c bits; the other W - [4] are c - 1 bits, unsigned),
+ * [5] buckets = 2^(c-1); *table_bytes (may be NULL): HBM held by the table */
+int msm_amd_bases_info(const msm_amd_bases *bases, uint32_t *out6, uint64_t *table_bytes);
+int msm_amd_multiexp_prepared(msm_amd_ctx *ctx, msm_amd_bases *bases, uint32_t flags, const void *scalars,
+                              uint32_t scalar_size, uint32_t n, uint8_t *out);
+int msm_amd_multiexp_prepared_async(msm_amd_ctx *ctx, msm_amd_bases *bases, uint32_t flags, const void *scalars,
+                                    uint32_t scalar_size, uint32_t n, uint64_t *ticket);
 
 /* ---- multi-GPU: one shard of the Pippenger windows -------------------------------------------- */
 /* Computes the contribution of windows {w : w % nshards == shard} (already weighted by 2^(c*w)),

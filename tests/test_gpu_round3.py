@@ -227,3 +227,167 @@ def test_bin_histogram_grows_between_calls(orc):
             assert C.g1m_multiexpAffine(bases, scalars, 32, n) == O.normalize(O.multiexp_affine(bases, scalars, 32, n)), c
     finally:
         eng.close()
+
+
+# ---- prepared bases (msm_amd_prepare_bases / msm_amd_multiexp_prepared) ------------------------------------------------
+@pytest.mark.parametrize("curve", ["bls12381", "bn128"])
+@pytest.mark.parametrize("group", [1, 2])
+def test_prepared_bases_reproduce_the_golden_records(eng, orc, curve, group):
+    """Every golden MSM record of the reference WASM (random sizes, n = 0 aside; all-zero / 1 / r-1 / r / 2^256-1 scalars, duplicate
+    points, P and -P, affine infinity among the inputs, all points equal, boundary scalars, scalar sizes 1..48, Jacobian bases with
+    Z != 1, Z = 1, Z = 0) through a table prepared for the record's scalar width: the same normalised bytes as the reference."""
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    zero = O.zero()
+    seen = 0
+    for rec in gu.golden(curve)["groups"][f"g{group}"]["msm"]:
+        if rec["n"] == 0:
+            continue
+        bases, scalars = gu.msm_inputs(curve, group, rec)
+        ss = rec["scalar_size"]
+        pb = C.prepare_bases(group, bases, rec["n"], scalar_bits=min(8 * ss, 512), jacobian_bases=rec["fn"] != "multiexpAffine")
+        try:
+            info = pb.info()
+            assert info["n"] == rec["n"] and info["windows"] * (info["c"] - 1) + info["signed_windows"] >= min(8 * ss, 512)
+            assert pb.multiexp(scalars, ss) == gu.canon(curve, group, bytes.fromhex(rec["out_norm"]), zero), rec["id"]
+            seen += 1
+        finally:
+            pb.release()
+    assert seen >= 20
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 20000), ("bn128", 1, 100000), ("bls12381", 2, 3000), ("bn128", 2, 2500), ("bls12381", 1, 3)])
+def test_prepared_bases_match_oracle_for_every_window_layout(eng, orc, curve, group, n):
+    """Seeded inputs, expected value from the oracle; the table is built for the default scalar width (the group order's bit length:
+    scalars are below r) with the window size the engine picks and with forced ones -- 3 bits (all windows unsigned 2-bit or signed
+    3-bit), 8 / 9 (one coarse bin), 13, 16, 17 (two-level partition), 20 / 21 (11 / 12 fine bits, 8-byte partition entries) -- then
+    prefixes of the points, device-resident scalars, and two calls in flight."""
+    import msm_amd
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, scalars = gu.random_case(curve, group, f"gpu:prep:{curve}:{group}:{n}", n)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    asz = C.affine_bytes(group)
+    try:
+        for c in (0, 3, 8, 9, 13, 16, 17, 20, 21):
+            eng.set_window_bits(c)
+            pb = C.prepare_bases(group, bases, n)
+            try:
+                info = pb.info()
+                if c:
+                    assert info["c"] == c
+                bits = 255 if curve == "bls12381" else 254
+                assert info["scalar_bits"] == bits and info["windows"] * (info["c"] - 1) + info["signed_windows"] >= bits
+                assert info["signed_windows"] < info["windows"] and info["table_bytes"] == info["windows"] * n * asz
+                eng.set_window_bits(0)                       # the call takes its layout from the table, not from the option
+                assert pb.multiexp(scalars) == exp, c
+                g = eng.geometry()
+                assert (g["c"], g["windows"], g["windows_owned"]) == (info["c"], info["windows"], 1)
+                if c in (0, 16):
+                    m = max(1, n // 3)
+                    assert pb.multiexp(scalars[:32 * m], 32, m) == O.normalize(O.multiexp_affine(bases[:asz * m], scalars[:32 * m], 32, m))
+                    d_s = eng.alloc(len(scalars)).upload(scalars)
+                    t1, t2 = pb.multiexp_async(d_s), pb.multiexp_async(scalars)
+                    with pytest.raises(msm_amd.MsmAmdError, match="in flight"):
+                        pb.release()
+                    assert t1.wait() == exp and t2.wait() == exp
+                    d_s.free()
+            finally:
+                pb.release()
+    finally:
+        eng.set_window_bits(0)
+
+
+def test_prepared_bases_edge_inputs_and_wide_scalars(eng, orc):
+    """Exceptional inputs on a prepared table -- affine infinity among the bases (its table column stays infinity), repeated points with
+    equal digits (the doubling branch inside a bucket that now collects ALL windows), P and -P, scalars 0 / 1 / r - 1 / 2^255 - 1, and the
+    carry chain of signed windows running into the unsigned top window -- and the width check: a scalar with a bit beyond the
+    prepared width fails loudly (the same inputs succeed on a table prepared for 256 bits, 2^256 - 1 included)."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 4000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    asz = 96
+    bases, scalars = gu.random_case(curve, group, "gpu:prep:edge", n)
+    bases = bytearray(bases)
+    bases[asz * 5:asz * 6] = bytes(asz)                                   # affine infinity
+    for i in range(200, 300):                                             # one point a hundred times
+        bases[asz * i:asz * (i + 1)] = bases[asz * 200:asz * 201]
+    y = int.from_bytes(bases[asz * 10 + 48:asz * 11], "little")          # -P = (x, q - y), also in Montgomery form
+    bases[asz * 11:asz * 12] = bases[asz * 10:asz * 10 + 48] + (gu.Q_MOD[curve] - y).to_bytes(48, "little")   # P and -P with equal scalars
+    bases = bytes(bases)
+    r = gu.R_ORDER[curve]
+    sc = bytearray(scalars)
+    special = [0, 1, r - 1, (1 << 255) - 1, (1 << 254), int("1" + "0" * 19, 2) << 100, ((1 << 255) - 1) ^ (1 << 19)]
+    for k, v in enumerate(special):
+        sc[32 * (400 + k):32 * (401 + k)] = v.to_bytes(32, "little")
+    for i in range(200, 300):
+        sc[32 * i:32 * (i + 1)] = sc[32 * 200:32 * 201]                   # equal scalars on the equal points: P + P in every bucket they meet in
+    sc[32 * 11:32 * 12] = sc[32 * 10:32 * 11]
+    scalars = bytes(sc)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    pb = C.prepare_bases(group, bases, n)                                 # 255 bits
+    try:
+        assert pb.multiexp(scalars) == gu.canon(curve, group, exp, O.zero())
+        wide = bytearray(scalars)
+        wide[32 * 77 + 31] |= 0x80                                        # bit 255 of one scalar
+        with pytest.raises(msm_amd.MsmAmdError, match="prepared for") as ei:
+            pb.multiexp(bytes(wide))
+        assert ei.value.code == msm_amd.EINVAL
+        assert pb.multiexp(scalars) == gu.canon(curve, group, exp, O.zero())      # the handle and the context stay usable
+        # 48-byte scalars whose upper 16 bytes are zero are served; a bit up there is not
+        s48 = b"".join(scalars[32 * i:32 * i + 32] + bytes(16) for i in range(n))
+        assert pb.multiexp(s48, 48) == gu.canon(curve, group, exp, O.zero())
+        w48 = bytearray(s48)
+        w48[48 * 9 + 40] = 1
+        with pytest.raises(msm_amd.MsmAmdError, match="prepared for"):
+            pb.multiexp(bytes(w48), 48)
+    finally:
+        pb.release()
+    pb = C.prepare_bases(group, bases, n, scalar_bits=256)
+    try:
+        wide = bytearray(scalars)
+        wide[32 * 77 + 31] |= 0x80
+        wide[32 * 78:32 * 79] = b"\xff" * 32                              # 2^256 - 1
+        expw = O.normalize(O.multiexp_affine(bases, bytes(wide), 32, n))
+        assert pb.multiexp(bytes(wide)) == gu.canon(curve, group, expw, O.zero())
+    finally:
+        pb.release()
+    # argument checks
+    with pytest.raises(msm_amd.MsmAmdError):
+        C.prepare_bases(group, bases, 0)
+    pb = C.prepare_bases(group, bases, 100)
+    try:
+        with pytest.raises(msm_amd.MsmAmdError, match="exceeds"):
+            pb.multiexp(scalars[:32 * 101], 32, 101)
+    finally:
+        pb.release()
+
+
+def test_prepared_bases_at_the_headline_size(eng, orc):
+    """n = 2^20 BLS12-381 G1 (the headline workload) on a prepared table: 13 windows of 20 / 19 bits over 2^19 buckets, the table
+    built on the GPU from resident bases; equals the general path on the same resident inputs; an oracle spot slice of the same
+    points through a prefix call."""
+    import torch
+    curve, group, n = "bls12381", 1, 1 << 20
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    pts = C.gen_points(group, 0xBA5E5, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    sc[:, 31] &= 0x3F
+    torch.cuda.synchronize()
+    pb = C.prepare_bases(group, pts, n)
+    try:
+        info = pb.info()
+        assert (info["c"], info["windows"], info["signed_windows"], info["buckets"]) == (20, 13, 8, 1 << 19)
+        full = C._multiexp(group, 0, pts, sc, 32, n)
+        assert pb.multiexp(sc) == full
+        assert eng.geometry()["entries"] > 12 * n
+        m = 3000
+        h_pts, h_sc = pts.download(m * 96), sc[:m].cpu().numpy().tobytes()
+        assert pb.multiexp(sc, 32, m) == O.normalize(O.multiexp_affine(h_pts, h_sc, 32, m))
+    finally:
+        pb.release()
+        pts.free()

@@ -162,6 +162,114 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Prepared bases: the window table of a fixed set of points (the SRS of a prover; reference caller shape
+// wasmcurves/benchmarks/multiexp.js:18-41: the same bases, call after call).
+// table[w][i] = 2^(start bit of window w) * P_i, affine.  With it the digit of EVERY window of scalar i selects a point that goes into
+// the SAME bucket set: the buckets, their reduction and the host's Horner loop shrink from W windows' worth to one, which in turn
+// lets the windows be wider -- n = 2^20: 13 windows of 20 / 19 bits over 2^19 buckets instead of 16 windows x 2^15 buckets:
+// 13 instead of 16 bucket additions per pair at the same number of buckets.
+// ------------------------------------------------------------------------------------------
+namespace msm {
+// next[i] = 2^ndbl * prev[i]: K points per lane, ndbl doublings each in extended Jacobian coordinates, back to affine with one shared
+// inversion per lane (Montgomery's trick, as k_jacobian_to_affine).  One-off work: loops are kept rolled.
+template <class F>
+__global__ void __launch_bounds__(256) k_table_next(const uint8_t* __restrict__ prev, uint32_t n, uint32_t ndbl, uint8_t* __restrict__ next) {
+    constexpr int K = 4;
+    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * K;
+    if (first >= n) return;
+    XYZZ<F> p[K];
+    F pref[K];
+    F acc = F::one();
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const uint32_t i = first + k;
+        XYZZ<F> q = XYZZ<F>::inf();
+        if (i < n) q = XYZZ<F>::from_affine(load16<Affine<F>>(prev + (size_t)i * sizeof(Affine<F>)));
+#pragma unroll 1
+        for (uint32_t d = 0; d < ndbl; ++d) q = XYZZ<F>::dbl(q);
+        p[k] = q;
+        pref[k] = acc;
+        if (!q.is_inf()) acc = F::mul(acc, F::mul(q.zz, q.zzz));
+    }
+    F inv = F::inv(acc);
+#pragma unroll 1
+    for (int k = K - 1; k >= 0; --k) {
+        const uint32_t i = first + k;
+        if (i >= n) continue;
+        Affine<F> a{F::zero(), F::zero()};
+        if (!p[k].is_inf()) {
+            const F t = F::mul(inv, pref[k]);          // 1 / (zz * zzz) of this point
+            inv = F::mul(inv, F::mul(p[k].zz, p[k].zzz));
+            a.x = F::mul(p[k].x, F::mul(t, p[k].zzz));   // x = X / ZZ
+            a.y = F::mul(p[k].y, F::mul(t, p[k].zz));    // y = Y / ZZZ
+        }
+        store16(next + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
+    }
+}
+}  // namespace msm
+
+// Window layout of a table for n points and scalars below 2^bits: `ns` signed windows of c bits followed by W - ns unsigned ones of
+// c - 1 bits (both kinds fill 2^(c-1) buckets evenly), the top one unsigned, W the fewest that cover `bits`, ns the fewest that do
+// it with W.  c minimises W x n bucket additions + the reduction of 2^(c-1) buckets (~6 additions' worth each, as pick_window_bits).
+static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t* c_out, uint32_t* W_out, uint32_t* ns_out) {
+    uint64_t best = ~0ull;
+    *c_out = *W_out = *ns_out = 0;
+    for (uint32_t c = 3; c <= (uint32_t)MAX_WINDOW_BITS; ++c) {
+        if (forced_c && c != forced_c) continue;
+        // W windows, ns of them signed (c bits), cover W (c - 1) + ns bits; ns <= W - 1 because the top window is unsigned
+        const uint32_t W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
+        const uint32_t ns = bits > W * (c - 1) ? bits - W * (c - 1) : 0u;
+        if ((uint64_t)W * n >= (1ull << 31)) continue;
+        const uint64_t cost = (uint64_t)W * n + 6ull * (1ull << (c - 1));
+        if (cost < best) {
+            best = cost;
+            *c_out = c;
+            *W_out = W;
+            *ns_out = ns;
+        }
+    }
+}
+
+template <class F>
+static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, uint32_t flags) {
+    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
+    const uint32_t n = h->n;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    h->table_bytes = (size_t)h->W * n * ASZ;
+    HIPCHK(ctx, hipMalloc(&h->table, h->table_bytes));
+    hipStream_t st = ctx->stream_s;
+    uint8_t* t0 = (uint8_t*)h->table;
+    const bool dev = (flags & (MSM_AMD_DEVICE_PTRS | MSM_AMD_DEVICE_BASES)) != 0;
+    if (flags & MSM_AMD_BASES_JACOBIAN) {
+        void* dj = const_cast<void*>(bases);
+        if (!dev) {
+            HIPCHK(ctx, hipMalloc(&dj, (size_t)n * JSZ));
+            if (hipMemcpyAsync(dj, bases, (size_t)n * JSZ, hipMemcpyHostToDevice, st) != hipSuccess) {
+                (void)hipFree(dj);
+                msm_set_err(ctx, "prepare_bases: copy of the bases failed");
+                return MSM_AMD_EHIP;
+            }
+        }
+        k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)dj, n, t0);
+        hipError_t e = hipStreamSynchronize(st);
+        if (!dev) (void)hipFree(dj);
+        HIPCHK(ctx, e);
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(t0, bases, (size_t)n * ASZ, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    Geom g{};
+    g.c = h->c;
+    g.ns = h->ns;
+    for (uint32_t w = 1; w < h->W; ++w) {
+        const uint32_t ndbl = window_start_bit(g, w) - window_start_bit(g, w - 1);
+        k_table_next<F><<<((n + 3) / 4 + 255) / 256, 256, 0, st>>>(t0 + (size_t)(w - 1) * n * ASZ, n, ndbl, t0 + (size_t)w * n * ASZ);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 struct RunArgs {
     const void* bases;
     const void* scalars;
@@ -169,6 +277,7 @@ struct RunArgs {
     uint32_t bit_lo, nbits;   // scalar bit range
     uint32_t shard, nshards;
     bool raw_out;             // un-normalised Jacobian partial (multi-GPU shard)
+    msm_amd_bases* prepared = nullptr;   // bases = the handle's window table (msm_amd_multiexp_prepared)
 };
 
 template <class F>
@@ -195,6 +304,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // the window size: by size and rank count -- except that option "glv" = 2 (tests, experiments) asks for the GLV schedule wherever it
     // applies, and that schedule is built on 16-bit windows
     auto window_bits = [&]() -> uint32_t {
+        if (a.prepared) return a.prepared->c;   // the table fixes the window layout
         uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (KernelField<F>::chained_variant ? 98304u : 65537u));
         if constexpr (GlvField<F>::value)
             if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
@@ -202,7 +312,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     };
     bool small_est;
     {
-        const uint32_t c0 = window_bits(), w0 = a.nbits / c0 + 1;
+        const uint32_t c0 = window_bits(), w0 = a.prepared ? 1u : a.nbits / c0 + 1;   // (prepared bases: one bucket set)
         small_est = (uint64_t)((w0 + a.nshards - 1) / a.nshards) << (c0 - 1) < 2u * 1024u * 64u;
     }
     if (small_est && !ctx->stream_s2) {
@@ -212,8 +322,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     }
     hipStream_t st = small_est ? ctx->stream_s2 : ctx->stream_s;
     const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
-    const bool dev_bases = dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
-    const bool jac = (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
+    const bool dev_bases = a.prepared || dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
+    const bool jac = !a.prepared && (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
     const size_t base_bytes = (size_t)a.n * (jac ? JSZ : ASZ);
     const size_t scalar_bytes = (size_t)a.n * a.scalar_size;
 
@@ -248,6 +358,15 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.half = 1u << (g.c - 1);
     g.shard = a.shard;
     g.nshards = a.nshards;
+    g.ns = g.W;
+    g.merged = 0;
+    g.stride = 0;
+    if (a.prepared) {   // the table's windows: ns signed of c bits, the rest unsigned of c - 1; all into ONE bucket set
+        g.W = a.prepared->W;
+        g.ns = a.prepared->ns;
+        g.merged = 1;
+        g.stride = a.prepared->n;
+    }
     // GLV path -- only for callers that vouch for their bases (flag MSM_AMD_BASES_IN_SUBGROUP, or option "glv" = 2): k*P = k1*P + k2*phi(P)
     // with k reduced mod r holds in the order-r subgroup only, while the reference's multiexp is plain integer arithmetic, exact for
     // ANY point of the curve (G1 has a ~2^126 cofactor).  Without the flag the engine keeps the reference's semantics.
@@ -259,7 +378,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // forces the path (tests, experiments).
     bool use_glv = false;
     if constexpr (GlvField<F>::value)
-        use_glv = (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+        use_glv = !a.prepared && (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
                   (a.n <= (1u << 18) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
     const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
@@ -270,9 +389,17 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.Wl = 0;
     for (uint32_t w = 0; w < g.W; ++w)
         if (w % g.nshards == g.shard) ++g.Wl;
+    if (g.merged) g.Wl = 1;
+    // entries one owned bucket set can receive: one per item -- one per item AND window when the windows share their buckets
+    const uint64_t nve64 = g.merged ? (uint64_t)g.W * nv : nv;
+    if (nve64 >= (1ull << 31) || (g.merged && (uint64_t)g.W * g.stride >= (1ull << 31))) {
+        msm_set_err(ctx, "windows x points of a prepared table must stay below 2^31");
+        return MSM_AMD_EINVAL;
+    }
+    const uint32_t nve = (uint32_t)nve64;
     // (pair, window) positions -- Mscan, offset, delta, the indices into tmp/sorted -- are 32-bit: the entries of one pass must
     // number fewer than 2^32 (17 windows x 2^27 points fit; 33 windows of 64-byte scalars or a forced narrow window would wrap)
-    if ((uint64_t)g.Wl * nv >= (1ull << 32)) {
+    if ((uint64_t)g.Wl * nve >= (1ull << 32)) {
         msm_set_err(ctx, "windows x points of one pass must stay below 2^32 (fewer points per call, a wider window, or the synchronous entry point with option \"slice\")");
         return MSM_AMD_EINVAL;
     }
@@ -310,7 +437,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_offset, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_order, (size_t)NB * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_bins, 2 * ORDER_KEYS * 4)) return rc;   // key populations, then the per-key cursors
-    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nv * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nve * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_flags, 16)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
     uint32_t* count = (uint32_t*)sl->d_count.p;
     uint32_t* offset = (uint32_t*)sl->d_offset.p;
@@ -340,7 +468,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         sg.cb = 1u << sg.cbits;
         sg.nbins = g.Wl * sg.cb;
         sg.idxbits = 1;
-        while ((1ull << sg.idxbits) < nv) ++sg.idxbits;
+        while ((1ull << sg.idxbits) < (g.merged ? (uint64_t)g.W * g.stride : (uint64_t)nv)) ++sg.idxbits;
         const bool e32 = sg.fbits + 1 + sg.idxbits <= 32;     // 4-byte partition entries {fine key | sign | index}
         // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
         // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
@@ -352,8 +480,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
-        const size_t max_chunks = ((size_t)g.Wl * nv) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
-        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nv * (e32 ? 4 : 8))) return rc;
+        const size_t max_chunks = ((size_t)g.Wl * nve) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * (e32 ? 4 : 8))) return rc;
         // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
         // well, ZeroMark in engine_ctx.hpp)
         if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
@@ -388,7 +516,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
         if (!sl->binhist_zero.holds(sl->d_binhist)) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
         sl->binhist_zero.clear();   // until this submission has got as far as k_bin_scan
-#define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist)
+        HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
+#define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist, (uint32_t*)sl->d_flags.p)
         if (wide) {
             if (nw == 8) MSM_TILE_HIST(8, 1024);
             else if (nw == 4) MSM_TILE_HIST(4, 1024);
@@ -436,8 +565,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
         // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
         // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
-        const uint32_t tb = g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u;   // scalar bits in the top window
-        const uint64_t mean_span = (uint64_t)nv / sg.cb;
+        // (a prepared table's windows all fill the bucket set evenly: no partly used top window)
+        const uint32_t tb = g.merged ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
+        const uint64_t mean_span = (uint64_t)nve / sg.cb;
         const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
         if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
@@ -479,7 +609,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // slot's own stream instead and may overlap the accumulations of the other calls in flight: measured better or equal whenever
     // the launch is short of ~1.5 rounds, also when its buckets are cut into slices (n = 2^20 over 4 ranks: 1.12 vs 1.25 ms per
     // call; n = 2^26 over 8 ranks: 25.2 vs 26.7).
-    const uint32_t mean = (nv + g.half - 1) / g.half;
+    const uint32_t mean = (nve + g.half - 1) / g.half;
     // lanes per bucket (k_accumulate_slices; 1 = the plain kernel).  Two reasons to cut buckets into slices, both measured on the
     // windows one rank of a sharded call owns (profiles/r02_slices_sweep.txt):
     //  (a) too few buckets to occupy the chip: bring the launch to ~320k lanes (five waves per SIMD, i.e. 1.67 rounds of the three
@@ -510,7 +640,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     };
     // segments are expected for the tail kernels when recent calls queued some (skewed scalars), when the segment length is forced,
     // and when the top window is only partly filled (few, dense buckets; the last rank of a 254-bit field)
-    const bool tail_expected = ctx->skew_hint.load() > 0 || ctx->force_seg != 0 || (g.nbits % g.c) != 0;
+    const bool tail_expected = ctx->skew_hint.load() > 0 || ctx->force_seg != 0 || (!g.merged && (g.nbits % g.c) != 0);
     const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
     const bool small_acc = ctx->acc_stream ? ctx->acc_stream == 1 : (NB < 5u * 1024u * 64u && !split_mode);
     st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
@@ -534,13 +664,13 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // as long as their chain stays below the launch's own duration (cap: 80 % of a lane slot's share of the additions).
         auto bound = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d + 8u * (uint64_t)std::ceil(std::sqrt((double)d)) + 8u, 1u << 24); };
         uint32_t seg_hi = bound(2ull * mean);
-        const uint32_t tb = g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u;   // scalar bits in the top window
+        const uint32_t tb = g.merged ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
         if (tb >= 12 && tb < g.c - 1) seg_hi = std::max(seg_hi, bound(2ull * (((uint64_t)nv + (1ull << tb) - 1) >> tb)));
-        const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nv) / 245760u, 1u << 20);
+        const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nve) / 245760u, 1u << 20);
         seg = std::max(seg, std::min(seg_hi, cap));
     }
     const uint32_t seg_min = (seg + std::max(k_first, k_second) - 1) / std::max(k_first, k_second);
-    const size_t max_segs = (size_t)g.Wl * nv / seg_min + 1;
+    const size_t max_segs = (size_t)g.Wl * nve / seg_min + 1;
     if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
@@ -624,7 +754,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
     }
     if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ)) return rc;
-    if (sl->h_partials_cap < (size_t)nparts * XSZ + 32) {
+    if (sl->h_partials_cap < (size_t)nparts * XSZ + 64) {
         if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
         sl->h_partials = nullptr;
         sl->h_partials_cap = 0;
@@ -661,6 +791,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
     // the tail counters of the (last) accumulation: buckets that overflowed their segment tell the next calls that the input is skewed
     HIPCHK(ctx, hipMemcpyAsync(h_tail + 2, sl->d_tailctl.p, 16, hipMemcpyDeviceToHost, sb));
+    HIPCHK(ctx, hipMemcpyAsync(h_tail + 6, sl->d_flags.p, 4, hipMemcpyDeviceToHost, sb));   // scalars wider than a prepared table's windows
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
     const uint32_t wgs_per_window = p0.wgs;
     sl->wgs_per_window = wgs_per_window;
@@ -698,6 +829,11 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         // calls of this context do (n = 2^20, 256-bit scalars: scatter stage 1.7 -> 0.3 ms from the second call on).
         if (h_tail[3] /* TailCtl::nbig */ > 0) ctx->skew_hint.store(16);
         else if (ctx->skew_hint.load() > 0) ctx->skew_hint.fetch_sub(1);
+        if (g.merged && h_tail[6]) {
+            msm_set_err(ctx, "a scalar has bits beyond the scalar_bits these bases were prepared for (msm_amd_prepare_bases): "
+                             "the table holds no window for them; prepare with a larger scalar_bits or use msm_amd_multiexp");
+            return MSM_AMD_EINVAL;
+        }
     }
 
     // ---- 6. host combine: window sums, Horner over owned windows (top first), each weighted 2^(c*w)
@@ -709,7 +845,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     HX total = HX::inf();
     int prev_w = -1;   // global index of the window most recently folded in
     for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
-        int wglob = wl * (int)g.nshards + (int)g.shard;
+        int wglob = g.merged ? 0 : wl * (int)g.nshards + (int)g.shard;   // (prepared table: the window weights are in the table)
         if (prev_w >= 0)
             for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = HX::dbl(total);
         HX s = HX::inf();
@@ -800,6 +936,8 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return rc;
     }
     sl->pending = true;
+    sl->prepared = a.prepared;
+    if (a.prepared) a.prepared->in_flight.fetch_add(1);
     sl->sync_owned = wait_for_slot;
     sl->ticket = ctx->next_ticket++;
     *ticket = sl->ticket;
@@ -832,6 +970,10 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         rc = found->finish(ctx, found, out);
+        if (found->prepared) {
+            found->prepared->in_flight.fetch_sub(1);
+            found->prepared = nullptr;
+        }
         found->pending = false;
         found->collecting = false;
         found->sync_owned = false;
@@ -1185,6 +1327,112 @@ int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
                            uint32_t scalar_size, uint32_t n, uint32_t shard, uint32_t nshards, uint8_t* out_partial) {
     RunArgs a{bases, scalars, scalar_size, n, flags, 0, scalar_size * 8, shard, nshards, true};
     return dispatch(ctx, curve, group, a, out_partial);
+}
+
+// ---- prepared bases --------------------------------------------------------------------------------------
+int msm_amd_prepare_bases(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, uint32_t n, uint32_t scalar_bits,
+                          msm_amd_bases** out) {
+    if (!ctx || !out) return MSM_AMD_EINVAL;
+    *out = nullptr;
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || !bases || n == 0 || scalar_bits > 512) {
+        msm_set_err(ctx, "prepare_bases: bad curve / group / bases / n / scalar_bits");
+        return MSM_AMD_EINVAL;
+    }
+    if ((flags & (MSM_AMD_DEVICE_PTRS | MSM_AMD_DEVICE_BASES)) && ((uintptr_t)bases & 15)) {
+        msm_set_err(ctx, "device bases pointer must be 16-byte aligned");
+        return MSM_AMD_EINVAL;
+    }
+    // 0: scalars reduced modulo the group order, what a prover's witness and quotient coefficients are (255 bits for BLS12-381, 254 for BN254)
+    if (scalar_bits == 0) scalar_bits = curve == MSM_AMD_BLS12381 ? 255 : 254;
+    msm_amd_bases* h = new (std::nothrow) msm_amd_bases();
+    if (!h) return MSM_AMD_ENOMEM;
+    h->ctx = ctx;
+    h->curve = curve;
+    h->group = group;
+    h->n = n;
+    h->scalar_bits = scalar_bits;
+    plan_prepared(n, scalar_bits, ctx->force_c >= 3 ? ctx->force_c : 0, &h->c, &h->W, &h->ns);
+    if (h->c == 0) {
+        delete h;
+        msm_set_err(ctx, "prepare_bases: windows x points of the table must stay below 2^31");
+        return MSM_AMD_EINVAL;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);   // (uses stream S; no call may be submitted meanwhile)
+    int rc;
+    if (curve == MSM_AMD_BLS12381 && group == 1) rc = build_table<Fp<Bls12381Fp>>(ctx, h, bases, flags);
+    else if (curve == MSM_AMD_BLS12381) rc = build_table<Fp2<Bls12381Fp>>(ctx, h, bases, flags);
+    else if (group == 1) rc = build_table<Fp<Bn254Fp>>(ctx, h, bases, flags);
+    else rc = build_table<Fp2<Bn254Fp>>(ctx, h, bases, flags);
+    if (rc) {
+        if (h->table) (void)hipFree(h->table);
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return 0;
+}
+
+int msm_amd_release_bases(msm_amd_ctx* ctx, msm_amd_bases* h) {
+    if (!ctx) return MSM_AMD_EINVAL;
+    if (!h) return 0;
+    if (h->ctx != ctx) {
+        msm_set_err(ctx, "release_bases: the handle belongs to another context");
+        return MSM_AMD_EINVAL;
+    }
+    if (h->in_flight.load() > 0) {
+        msm_set_err(ctx, "release_bases: calls on these bases are still in flight (wait for their tickets first)");
+        return MSM_AMD_EINVAL;
+    }
+    (void)hipSetDevice(ctx->device);
+    if (h->table) (void)hipFree(h->table);
+    delete h;
+    return 0;
+}
+
+int msm_amd_bases_info(const msm_amd_bases* h, uint32_t* out6, uint64_t* table_bytes) {
+    if (!h || !out6) return MSM_AMD_EINVAL;
+    out6[0] = h->n;
+    out6[1] = h->scalar_bits;
+    out6[2] = h->c;
+    out6[3] = h->W;
+    out6[4] = h->ns;
+    out6[5] = 1u << (h->c - 1);
+    if (table_bytes) *table_bytes = h->table_bytes;
+    return 0;
+}
+
+static int prepared_args(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, RunArgs* a) {
+    if (!ctx || !h) return MSM_AMD_EINVAL;
+    if (h->ctx != ctx) {
+        msm_set_err(ctx, "multiexp_prepared: the bases were prepared on another context");
+        return MSM_AMD_EINVAL;
+    }
+    if (n > h->n) {
+        msm_set_err(ctx, "multiexp_prepared: n exceeds the number of prepared points");
+        return MSM_AMD_EINVAL;
+    }
+    if (flags & ~(uint32_t)MSM_AMD_DEVICE_PTRS) {
+        msm_set_err(ctx, "multiexp_prepared: the only flag is MSM_AMD_DEVICE_PTRS (scalars resident on the GPU)");
+        return MSM_AMD_EINVAL;
+    }
+    *a = RunArgs{h->table, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false, h};
+    return 0;
+}
+// R = sum_{i < n} scalar_i * P_i over the first n prepared points
+int msm_amd_multiexp_prepared(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, uint8_t* out) {
+    RunArgs a;
+    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a)) return rc;
+    if (!out) return MSM_AMD_EINVAL;
+    uint64_t t = 0;
+    if (int rc = submit(ctx, h->curve, h->group, a, &t, true)) return rc;
+    return finish_ticket(ctx, t, out);
+}
+int msm_amd_multiexp_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n,
+                                    uint64_t* ticket) {
+    RunArgs a;
+    if (!ticket) return MSM_AMD_EINVAL;
+    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a)) return rc;
+    return submit(ctx, h->curve, h->group, a, ticket);
 }
 
 #define BY_FIELD(curve, group, CALL)                                                         \

@@ -48,7 +48,15 @@ struct Geom {
     uint32_t half;          // buckets per window = 2^(c-1)
     uint32_t shard, nshards;   // this call owns windows w with w % nshards == shard
     uint32_t Wl;            // number of owned windows
+    // Prepared bases (msm_amd_prepare_bases: a table of 2^(start bit of window w) * P_i for every window w): all windows share ONE
+    // bucket set (`merged`; Wl = 1), and entry (i, w) addresses table point w * stride + i.  The windows are then of two kinds, both
+    // filling the same 2^(c-1) buckets evenly: the first `ns` are c bits wide and signed (digit in [-2^(c-1), 2^(c-1)], carry out),
+    // the rest c - 1 bits wide and unsigned (digit + carry in [0, 2^(c-1)], no carry out -- so the top window never spills into a
+    // further one).  Calls on caller-supplied bases have merged = 0 and ns = W: every window c bits, signed.
+    uint32_t merged, ns, stride;
 };
+// first scalar bit of window w
+MSM_HD uint32_t window_start_bit(const Geom& g, uint32_t w) { return w <= g.ns ? w * g.c : g.ns * g.c + (w - g.ns) * (g.c - 1u); }
 
 
 }  // namespace msm

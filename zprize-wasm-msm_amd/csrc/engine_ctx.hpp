@@ -76,8 +76,10 @@ struct Slot {
     Geom g{};
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
+    msm_amd_bases* prepared = nullptr;   // the call runs on a prepared table (released from in_flight when collected)
+    DevBuf d_flags;                      // word 0: a scalar had bits beyond the windows of the prepared table
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
-    DevBuf* bufs[24] = {&d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+    DevBuf* bufs[25] = {&d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
 
@@ -85,6 +87,18 @@ constexpr uint32_t MAX_SLICES = 64;   // lanes per bucket of a sliced accumulati
 
 struct msm_nccl_id {   // ncclUniqueId (rccl.h: 128 opaque bytes, passed by value)
     char internal[128];
+};
+
+// Prepared bases (msm_amd_prepare_bases): the window table of a fixed set of points, resident in HBM.
+struct msm_amd_bases {
+    msm_amd_ctx* ctx = nullptr;
+    int curve = 0, group = 0;
+    uint32_t n = 0;             // points
+    uint32_t scalar_bits = 0;   // the windows cover scalars below 2^scalar_bits
+    uint32_t c = 0, W = 0, ns = 0;   // window layout (Geom: ns windows of c bits, signed, then W - ns of c - 1 bits, unsigned)
+    void* table = nullptr;      // [W][n] affine points, the reference's packed Montgomery image: table[w][i] = 2^(start bit of window w) * P_i
+    size_t table_bytes = 0;
+    std::atomic<int> in_flight{0};   // calls submitted and not yet collected (release refuses while > 0)
 };
 
 struct msm_amd_ctx {

@@ -90,24 +90,43 @@ struct DigitSource {
             }
         }
     }
-    // digit of item k in window `win` (windows must be visited in order 0, 1, 2, ...)
+    // digit of item k in window `win` (windows must be visited in order 0, 1, 2, ...).  Windows below g.ns are c bits wide and
+    // signed; the rest (prepared bases only) c - 1 bits wide and unsigned: they absorb a carry, never produce one.
     MSM_D void next(const uint8_t* __restrict__ scalars, const Geom& g, int k, uint32_t win, uint32_t& mag, bool& neg) {
+        const bool sgn = win < g.ns;
+        const uint32_t wb = sgn ? g.c : g.c - 1u;
         uint32_t raw;
         if constexpr (NW > 0) {
-            raw = w[k][0] & ((1u << g.c) - 1u);   // bits beyond the scalar are zero by construction
+            raw = w[k][0] & ((1u << wb) - 1u);   // bits beyond the scalar are zero by construction
 #pragma unroll
-            for (int q = 0; q < NW - 1; ++q) w[k][q] = __builtin_amdgcn_alignbit(w[k][q + 1], w[k][q], g.c);
-            w[k][NW - 1] >>= g.c;
+            for (int q = 0; q < NW - 1; ++q) w[k][q] = __builtin_amdgcn_alignbit(w[k][q + 1], w[k][q], wb);
+            w[k][NW - 1] >>= wb;
         } else {
-            const uint32_t off = win * g.c;
-            const uint32_t nb = off >= g.nbits ? 0u : min(g.c, g.nbits - off);
+            const uint32_t off = window_start_bit(g, win);
+            const uint32_t nb = off >= g.nbits ? 0u : min(wb, g.nbits - off);
             raw = (valid >> k) & 1u ? scalar_bits(scalars, g, first + k * BLOCK, g.bit_lo + off, nb) : 0u;
         }
         raw += (carry >> k) & 1u;
-        const bool negd = raw > g.half;
+        const bool negd = sgn && raw > g.half;
         mag = negd ? (1u << g.c) - raw : raw;
         carry = negd ? (carry | (1u << k)) : (carry & ~(1u << k));
         neg = negd != (((flip >> k) & 1u) != 0);
+    }
+    // After the last window: does item k hold scalar bits beyond the windows?  (Prepared bases cover the scalar width they were
+    // prepared for; a wider scalar cannot be served by the table and is reported, never silently truncated.)
+    MSM_D bool leftover(const uint8_t* __restrict__ scalars, const Geom& g, int k) const {
+        if constexpr (NW > 0) {
+            uint32_t any = 0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) any |= w[k][q];
+            return any != 0;
+        } else {
+            if (!((valid >> k) & 1u)) return false;
+            uint32_t any = 0;
+            for (uint32_t off = window_start_bit(g, g.W); off < g.nbits; off += 24u)
+                any |= scalar_bits(scalars, g, first + k * BLOCK, g.bit_lo + off, min(24u, g.nbits - off));
+            return any != 0;
+        }
     }
 };
 
@@ -159,7 +178,8 @@ struct SortGeom {
 // (LDS histogram per tile, then one global atomic per non-empty (window, bin): ~2000 counters shared by all tiles)
 // ------------------------------------------------------------------------------------------
 template <int NW, int ITEMS, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ binhist) {
+__global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ binhist,
+                                                      uint32_t* __restrict__ too_wide) {
     extern __shared__ uint32_t smem_u32[];
     uint32_t* h = smem_u32;   // [Wl][cb]
     const uint32_t tile = blockIdx.x;
@@ -168,8 +188,8 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
     DigitSource<NW, ITEMS, BLOCK> ds;
     ds.load(scalars, g, tile * (ITEMS * BLOCK));
     for (uint32_t w = 0; w < g.W; ++w) {
-        const bool owned = (w % g.nshards) == g.shard;
-        const uint32_t wl = w / g.nshards;
+        const bool owned = g.merged || (w % g.nshards) == g.shard;
+        const uint32_t wl = g.merged ? 0u : w / g.nshards;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             uint32_t mag;
@@ -177,6 +197,12 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
             ds.next(scalars, g, k, w, mag, neg);
             if (owned && mag != 0) atomicAdd(&h[wl * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
         }
+    }
+    if (g.merged) {   // (uniform) scalar bits the table has no window for
+        bool wide = false;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) wide |= ds.leftover(scalars, g, k);
+        if (wide) atomicOr(too_wide, 1u);
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < sg.nbins; s += BLOCK) {
@@ -309,7 +335,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
 #pragma unroll
         for (int gw = 0; gw < GW; ++gw) {
             const uint32_t w = w0 + gw;
-            const bool owned = w < g.W && (w % g.nshards) == g.shard;
+            const bool owned = w < g.W && (g.merged || (w % g.nshards) == g.shard);
             any |= owned;
             negm[gw] = livem[gw] = 0;
 #pragma unroll
@@ -332,7 +358,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
         // every non-empty run reserves its span of the bin
         for (uint32_t s = t; s < ncnt; s += BLOCK) {
             const uint32_t w = w0 + s / sg.cb, bin = s % sg.cb, cnt = hs[s];
-            gb[s] = cnt ? atomicAdd(&cursor[(w / g.nshards) * sg.cb + bin], cnt) : 0u;   // cnt != 0 only for owned windows
+            gb[s] = cnt ? atomicAdd(&cursor[(g.merged ? 0u : w / g.nshards) * sg.cb + bin], cnt) : 0u;   // cnt != 0 only for owned windows
         }
         const uint32_t staged = block_exclusive_scan<BLOCK>(hs, ncnt, wsum);   // hs: start of each run inside the staged group
 #pragma unroll
@@ -341,7 +367,8 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
             for (int k = 0; k < ITEMS; ++k) {
                 if ((livem[gw] >> k) & 1u) {
                     const uint32_t b = mr[gw][k] >> 12, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
-                    stage[slot] = make_entry<E>(ds.first + k * BLOCK, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
+                    // (prepared bases: the entry addresses the table point of this window, w * stride + i)
+                    stage[slot] = make_entry<E>((g.merged ? (w0 + gw) * g.stride : 0u) + ds.first + k * BLOCK, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
                     srun[slot] = (uint16_t)run;
                 }
             }

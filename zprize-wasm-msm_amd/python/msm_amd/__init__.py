@@ -90,6 +90,11 @@ def load_library(path=None):
     L.msm_amd_dist_plan.argtypes = [vp, c.c_int, c.c_int, u32, u32, u32, u32] + [c.POINTER(u32)] * 4
     L.msm_amd_multiexp_dist_local.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, u8p]
     L.msm_amd_multiexp_dist_local_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u32, c.POINTER(c.c_uint64)]
+    L.msm_amd_prepare_bases.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, u32, c.POINTER(vp)]
+    L.msm_amd_release_bases.argtypes = [vp, vp]
+    L.msm_amd_bases_info.argtypes = [vp, c.POINTER(u32), c.POINTER(c.c_uint64)]
+    L.msm_amd_multiexp_prepared.argtypes = [vp, vp, u32, vp, u32, u32, u8p]
+    L.msm_amd_multiexp_prepared_async.argtypes = [vp, vp, u32, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_normalize.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_to_affine.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
@@ -267,6 +272,41 @@ class Ticket:
         return out.raw
 
 
+class PreparedBases:
+    """Handle of msm_amd_prepare_bases: the window table of a fixed set of points, resident in HBM.  multiexp / multiexp_async run an
+    MSM over the first n of them (all of them by default); release() frees the table."""
+
+    def __init__(self, curve, group, handle, n):
+        self.curve, self.group, self.handle, self.n = curve, group, handle, n
+
+    def info(self):
+        arr = (ctypes.c_uint32 * 6)()
+        tb = ctypes.c_uint64()
+        self.curve.eng.L.msm_amd_bases_info(self.handle, arr, ctypes.byref(tb))
+        return {"n": arr[0], "scalar_bits": arr[1], "c": arr[2], "windows": arr[3], "signed_windows": arr[4], "buckets": arr[5],
+                "table_bytes": tb.value}
+
+    def multiexp(self, scalars, scalar_size=32, n=None):
+        ps, dev_s, ks = _as_ptr(scalars)
+        out = ctypes.create_string_buffer(self.curve.jacobian_bytes(self.group))
+        eng = self.curve.eng
+        eng._chk(eng.L.msm_amd_multiexp_prepared(eng.ctx, self.handle, FLAG_DEVICE if dev_s else 0, ps, scalar_size, self.n if n is None else n, out))
+        return out.raw
+
+    def multiexp_async(self, scalars, scalar_size=32, n=None):
+        ps, dev_s, ks = _as_ptr(scalars)
+        t = ctypes.c_uint64()
+        eng = self.curve.eng
+        eng._chk(eng.L.msm_amd_multiexp_prepared_async(eng.ctx, self.handle, FLAG_DEVICE if dev_s else 0, ps, scalar_size,
+                                                       self.n if n is None else n, ctypes.byref(t)))
+        return Ticket(self.curve, self.group, t.value, (ks, self))
+
+    def release(self):
+        if self.handle:
+            self.curve.eng._chk(self.curve.eng.L.msm_amd_release_bases(self.curve.eng.ctx, self.handle))
+            self.handle = None
+
+
 class DistTicket(Ticket):
     """Handle of a queued sharded MSM of a multi-GPU group; wait() exchanges the partials over RCCL and returns the sum."""
 
@@ -352,6 +392,16 @@ class Curve:
 
     # the opt-path signature (wasmcurves/src/build_multiexp_opt.js:1987-1996): scalarSize fixed at 32
     def g1m_multiexp_multiExp(self, points, scalars, n): return self.g1m_multiexpAffine(points, scalars, 32, n)
+
+    # --- prepared bases (msm_amd_prepare_bases): a prover's fixed points, set up once ---------------------
+    def prepare_bases(self, group, bases, n, scalar_bits=0, jacobian_bases=False):
+        """The window table of n fixed points (host bytes or a device buffer), built on the GPU once; returns a PreparedBases.
+        scalar_bits = 0: scalars below the group order."""
+        pb, dev_b, kb = _as_ptr(bases)
+        flags = (FLAG_JACOBIAN if jacobian_bases else 0) | (FLAG_DEVICE if dev_b else 0)
+        h = ctypes.c_void_p()
+        self.eng._chk(self.eng.L.msm_amd_prepare_bases(self.eng.ctx, self.cid, group, flags, pb, n, scalar_bits, ctypes.byref(h)))
+        return PreparedBases(self, group, h, n)
 
     # --- multi-GPU building blocks --------------------------------------------------------------
     def multiexp_shard(self, group, bases, scalars, scalar_size, n, shard, nshards, jacobian_bases=False):
