@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--resident-bases", action="store_true", help="with --host-buffers: keep the bases on the GPU, copy only the scalars")
     ap.add_argument("--depth", type=int, default=0, help="calls in flight when pipelined (default 2; 4 for more than four ranks)")
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
+    ap.add_argument("--prepared", action="store_true", help="the bases are PREPARED once outside the timed region (msm_amd_prepare_bases: the window table of a prover's "
+                    "fixed SRS) and every step is msm_amd_multiexp_prepared; prints its own line -- the default line stays the general path (N = 1 only)")
     args = ap.parse_args()
 
     # --gpus N > 1 without a launcher around us (python bench.py --gpus N): start the N ranks ourselves.  This happens before torch,
@@ -199,6 +201,14 @@ def main():
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
+    prep = None
+    if args.prepared:
+        if sharded or args.host_buffers:
+            sys.exit("bench.py: --prepared is a one-GPU, resident-inputs mode")
+        t_prep = time.perf_counter()
+        prep = C.prepare_bases(g, pts, n)
+        torch.cuda.synchronize()
+        t_prep = time.perf_counter() - t_prep
     h_pts = h_sc = None
     if args.host_buffers:
         import numpy as np
@@ -247,6 +257,8 @@ def main():
             return C.multiexp_dist_local(g, pts, d_scalars, 32, count, n)
         if args.host_buffers:
             return C._multiexp(g, 0, pts if args.resident_bases else h_pts, h_sc, 32, n)
+        if prep is not None:
+            return prep.multiexp(d_scalars)
         if not sharded:
             return C._multiexp(g, 0, pts, d_scalars, 32, n)
         # this rank's windows of its slice; ONE all_gather of world x 144 B over RCCL/xGMI; host adds the partials
@@ -269,7 +281,19 @@ def main():
     # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
     # windows are sharded 8 ways the accumulation per rank shrinks but the reduction latency does not, so more are needed
     # (tools/bench_shard.py on one GPU: 2 in flight is best up to 4 ranks, 4 at 8 ranks)
-    depth = 1 if not pipelined else (args.depth or (2 if world <= 4 else 4))
+    # How many: one probe call tells what a call of this rank consists of (profiles/r03_shard_per_rank_table.txt, both depths
+    # measured for every share): four in flight pay when the share is one of several window groups AND small (fewer than ~4 M
+    # (pair, window) entries: its accumulation then runs on its slot's own stream beside the others'); two otherwise.
+    depth = 1
+    if pipelined:
+        depth = args.depth or 2
+        if sharded and not args.depth and plan["gw"] > 1:
+            C.multiexp_shard(g, pts, d_scalars, 32, count, rank % plan["gw"], plan["gw"])
+            gm = eng.geometry()
+            small = gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["windows_owned"] * count < (1 << 22)
+            flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=xdev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank keeps the same number of calls in flight
+            depth = 4 if int(flag.item()) == 1 else 2
     eng.set_option("slots", max(depth, 1))
 
     xch = mdist.PartialExchange(args.curve, g, device=xdev) if sharded else None
@@ -291,7 +315,9 @@ def main():
             # `depth` steps in flight: the bucket reduction of step i (stream B) overlaps the sort + accumulation of step i+1 (stream A)
             inflight = []
             for _ in range(steps):
-                if not sharded:
+                if prep is not None:
+                    inflight.append(prep.multiexp_async(d_scalars))
+                elif not sharded:
                     inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))
                 else:
                     inflight.append(C.multiexp_dist_local_async(g, pts, d_scalars, 32, count, n) if cabi else C.multiexp_shard_async(g, pts, d_scalars, 32, count, rank % gw, gw))
@@ -356,7 +382,7 @@ def main():
         # HBM bytes of one k_accumulate launch from the hardware counters (rocprofv3 --pmc, its own run: profiles/pmc_accumulate.json);
         # only quoted for the workload it was measured on
         traffic = None
-        headline = (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["c"] == 16 and geom["windows"] == 17 and not sharded
+        headline = (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["c"] == 16 and geom["windows"] == 17 and not sharded and prep is None
         pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
         if headline and os.path.exists(pmc):
             try:
@@ -378,8 +404,8 @@ def main():
                 sc_traffic = None
         mads = MADS_PER_ADD.get((args.curve, g))
         out = {
-            "metric": "BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
-                      else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}",
+            "metric": ("BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
+                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}") + (" -- PREPARED BASES (not the headline path)" if prep is not None else ""),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)" if args.curve == "bls12381" else "u32 limbs (254-bit Montgomery integers)",
@@ -387,6 +413,9 @@ def main():
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
+                       "bases": ("caller-supplied per call (the reference's interface: msm_amd_multiexp)" if prep is None else
+                                 {"form": "prepared once outside the timed region (msm_amd_prepare_bases); every step is msm_amd_multiexp_prepared",
+                                  **prep.info(), "prepare_s": t_prep}),
                        "parallelism": "1 GPU" if not sharded else f"{plan['gp']} point slices x {plan['gw']} window groups over {world} GPUs (every rank holds only its slice) + ONE RCCL all_gather of the partials",
                        "split": None if not sharded else {"gp": plan["gp"], "gw": plan["gw"], "points_per_rank": count},
                        "exchange": exchange},
@@ -433,6 +462,8 @@ def main():
         if not args.no_cpu_baseline and not sharded:
             out["cpu_baseline"] = cpu_baseline(args, pts, sc_host, n, result)
         print(json.dumps(out), flush=True)
+    if prep is not None:
+        prep.release()
     pts.free()
     eng.close()
     if sharded:

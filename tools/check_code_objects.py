@@ -5,7 +5,7 @@ Why: twice in round 1 a build whose NON-KERNEL device functions had grown past t
 take a signed 16-bit dword offset: +-128 KiB) hung the GPU on its first BLS12-381 G2 call.  Such a function is
 the only place where the compiler's long-branch expansion (s_getpc_b64 / s_add_u32 / s_addc_u32 / s_setpc_b64 on a scavenged SGPR
 pair) appears inside a callee.  The build therefore fails when
-  * a non-kernel FUNC symbol of any embedded code object is larger than LIMIT bytes (default 120 KiB), or
+  * a non-kernel FUNC symbol of any embedded code object is larger than LIMIT bytes (default 100 KiB: the largest shipped function is 89 KB, 123 KB is known to run and 136 KB to hang), or
   * a non-kernel function contains an s_setpc_b64 through anything but the return address s[30:31] (a relaxed long branch),
 so that the next inlining change cannot silently bring the hang back.  Kernels are exempt (500-KiB kernels run fine).
 
@@ -88,7 +88,7 @@ def main(argv):
     if len(argv) < 2:
         print(__doc__)
         return 2
-    limit = 120 * 1024
+    limit = 100 * 1024
     if "--limit" in argv:
         limit = int(argv[argv.index("--limit") + 1])
     objs = code_objects(argv[1])

@@ -83,7 +83,6 @@ def main():
         n = 1 << logn
         base = None
         for world in a.worlds:
-            depth = 2 if world <= 4 else 4
             plan = eng.dist_plan(a.curve, g, 32, n, world, 0)
             rows = []
             for gw in range(1, world + 1):
@@ -91,23 +90,40 @@ def main():
                     continue
                 gp = world // gw
                 count = (n + gp - 1) // gp
-                ms0, c = share(count, 0, gw, depth)
-                ms1 = share(count, gw - 1, gw, depth)[0] if gw > 1 else ms0
-                rows.append({"gp": gp, "gw": gw, "points_per_rank": count, "c": c, "ms_w0": ms0, "ms_wlast": ms1, "ms_busiest": max(ms0, ms1)})
+                # two and four calls in flight: what pays depends on the size of the share (bench.py keeps four in flight when the
+                # share's accumulation is small enough to run on the slots' own streams, two otherwise)
+                per_depth = {}
+                for depth in (2, 4):
+                    ms0, c = share(count, 0, gw, depth)
+                    ms1 = share(count, gw - 1, gw, depth)[0] if gw > 1 else ms0
+                    per_depth[depth] = max(ms0, ms1)
+                depth = min(per_depth, key=per_depth.get)
+                rows.append({"gp": gp, "gw": gw, "points_per_rank": count, "c": c, "ms_depth2": per_depth[2], "ms_depth4": per_depth[4],
+                             "calls_in_flight": depth, "ms_busiest": per_depth[depth]})
             best = min(rows, key=lambda r: r["ms_busiest"])
             chosen = next(r for r in rows if r["gw"] == plan["gw"])
             if world == 1:
                 base = chosen["ms_busiest"]
-            rec = {"logn": logn, "ranks": world, "calls_in_flight": depth, "splits": rows, "planned": {"gp": plan["gp"], "gw": plan["gw"]},
+            rec = {"logn": logn, "ranks": world, "splits": rows, "planned": {"gp": plan["gp"], "gw": plan["gw"]},
                    "planned_ms": chosen["ms_busiest"], "best": {"gp": best["gp"], "gw": best["gw"]}, "best_ms": best["ms_busiest"],
                    "one_gpu_ms": base, "speedup_planned_before_exchange": (base / chosen["ms_busiest"]) if base else None}
             if out:
                 out.write(json.dumps(rec) + "\n")
                 out.flush()
-            cells = "  ".join(f"{r['gp']}x{r['gw']}(c={r['c']}): {r['ms_busiest']:.3f}" for r in rows)
+            cells = "  ".join(f"{r['gp']}x{r['gw']}(c={r['c']},d{r['calls_in_flight']}): {r['ms_busiest']:.3f}" for r in rows)
             sp = f"{base / chosen['ms_busiest']:.2f}x" if base else "-"
             print(f"n=2^{logn} ranks={world}: {cells}   planned {plan['gp']}x{plan['gw']} = {chosen['ms_busiest']:.3f} ms ({sp} of one GPU)"
                   f"{'' if (best['gp'], best['gw']) == (plan['gp'], plan['gw']) else f'   BEST {best_str(best)}'}", flush=True)
+    # the same measurements by (points per rank, window groups): what the split policy's cost table is made of
+    print("# per-share cost: log2(points per rank), window groups -> ms at 2 | 4 calls in flight (window group 0)")
+    shares = {}
+    for (count, w, gw, depth), (ms, c) in sorted(memo.items()):
+        if w == 0:
+            shares.setdefault((count, gw), {})[depth] = ms
+    for (count, gw), d in sorted(shares.items()):
+        print(f"share n_slice={count} gw={gw}: " + " | ".join(f"{d.get(k, float('nan')):.3f}" for k in (2, 4)))
+    if out:
+        out.write(json.dumps({"shares": [{"points": c_, "gw": g_, "ms_depth2": d.get(2), "ms_depth4": d.get(4)} for (c_, g_), d in sorted(shares.items())]}) + "\n")
     pts.free()
     eng.close()
 

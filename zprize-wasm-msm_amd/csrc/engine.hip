@@ -86,7 +86,10 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
         for (uint32_t cand : {16u, 19u, 20u}) {
             if (cand > nbits) continue;
             const uint32_t w = (nbits + cand - 1) / cand;   // windows that receive scalar bits (a further carry-only window is negligible)
-            uint64_t cost = (uint64_t)((w + nshards - 1) / nshards) * ((uint64_t)n + 6ull * (1ull << (cand - 1)));
+            // (the bucket term: ~3 additions' worth per bucket when its reduction overlaps the next call's accumulation -- measured at
+            // n = 2^23, two calls in flight: 21.20 ms at c = 16, 21.73 at 19, 20.85 at 20, profiles/r03_sweep_prepared_window_bits.txt;
+            // a lone call pays ~5 per bucket and is level there, 21.83 against 21.80)
+            uint64_t cost = (uint64_t)((w + nshards - 1) / nshards) * ((uint64_t)n + 3ull * (1ull << (cand - 1)));
             // a top window of fewer than 12 bits (c = 19 over 256 bits: 9) has a few hundred buckets of n / 2^tb entries each, which go
             // through the tail kernels at half the efficiency: count it twice (n = 2^24, ms per MSM at c = 19 | 20: BN254 20.8 | 20.2,
             // BLS12-381 40.5 | 37.8 -- k_accumulate_tail + k_combine_tail took 2.6 of BN254's 20.8)
@@ -122,18 +125,37 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
 // windows keeps the populations and divides the buckets -- and with them the latency-bound reduction, which is what a small call
 // consists of.  The estimate below is the per-rank cost model fitted to the measurements of tools/bench_shard.py (one rank's share run
 // alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
-static double shard_cost_ms(const msm_amd_ctx* ctx, uint32_t n_slice, uint32_t nbits, uint32_t gw, bool g1, double add_ns) {
+// kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
+// many points, run alone on one MI355X with two or four calls in flight, whichever is faster (BLS12-381 G1, 255-bit scalars;
+// tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
+// Other curves and groups scale the table; the choice of a split only needs its shape.
+static const float kShareMs[14][4] = {
+    {0.406f, 0.420f, 0.360f, 0.400f},       // 2^13
+    {0.467f, 0.422f, 0.357f, 0.400f},       // 2^14
+    {0.576f, 0.433f, 0.357f, 0.398f},       // 2^15
+    {0.800f, 0.487f, 0.383f, 0.398f},       // 2^16
+    {1.092f, 0.581f, 0.428f, 0.450f},       // 2^17
+    {1.260f, 0.741f, 0.541f, 0.503f},       // 2^18
+    {1.626f, 1.044f, 0.736f, 0.600f},       // 2^19
+    {2.581f, 1.556f, 0.947f, 0.720f},       // 2^20
+    {5.211f, 3.024f, 1.620f, 1.170f},       // 2^21
+    {10.946f, 6.049f, 3.144f, 1.913f},      // 2^22
+    {21.365f, 11.124f, 6.387f, 3.500f},     // 2^23
+    {37.102f, 21.665f, 11.681f, 6.415f},    // 2^24
+    {70.500f, 39.511f, 22.895f, 12.300f},   // 2^25
+    {137.072f, 77.712f, 45.111f, 23.623f},  // 2^26
+};
+static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
     if (n_slice == 0) return 0.0;
-    const uint32_t c = pick_window_bits(n_slice, nbits, ctx->force_c, gw, ctx->no_split2 ? 4096u : (g1 ? 98304u : 65537u));
-    const uint32_t W = nbits / c + 1, own = (W + gw - 1) / gw;
-    const double half = (double)(1u << (c - 1)), nb_own = own * half, adds = (double)own * n_slice;
-    // accumulation: launches short of ~5 waves per SIMD (327680 buckets) run sliced, with a join, at ~85 % of the full rate
-    const double acc = adds * add_ns * (nb_own >= 327680.0 ? 1.0 : 1.0 / 0.85) * 1e-6;
-    // reduction: two full additions per bucket at about half the accumulation's rate, and never less than its dependent chain
-    const double red = std::max(0.30, nb_own * 2.0 * add_ns * 2.2 * 1e-6);
-    // sort: ~0.12 ms of launches, then ~10 us per million (pair, window) entries
-    const double sort = 0.12 + adds * 1.0e-8;
-    return sort + acc + red;
+    const double lx = std::log2((double)n_slice), x = std::min(std::max(lx - 13.0, 0.0), 13.0);
+    const double y = std::min(std::max(std::log2((double)gw), 0.0), 3.0);
+    const int x0 = std::min((int)x, 12), y0 = std::min((int)y, 2);
+    const double fx = x - x0, fy = y - y0;
+    auto at = [&](int i, int j) { return std::log((double)kShareMs[i][j]); };   // interpolated in log space
+    double t = std::exp((1 - fx) * ((1 - fy) * at(x0, y0) + fy * at(x0, y0 + 1)) + fx * ((1 - fy) * at(x0 + 1, y0) + fy * at(x0 + 1, y0 + 1)));
+    if (lx > 26.0) t *= (double)n_slice / 67108864.0;   // beyond the table: linear in the points
+    if (gw > 8) t *= 8.0 / gw;                          // (more window groups than measured: fewer windows each)
+    return t;
 }
 void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw) {
     *gp = 1;
@@ -144,17 +166,19 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
         *gp = world / ctx->dist_gw;
         return;
     }
-    const uint32_t nbits = scalar_size * 8;
-    // ns per bucket addition of the accumulation kernels on one MI355X (BLS12-381 G1: 6.9-8.1 G additions per second)
-    const double add_ns = (curve == MSM_AMD_BLS12381 ? 0.140 : 0.066) * (group == 2 ? 3.2 : 1.0);
+    (void)curve;
+    (void)group;
+    (void)scalar_size;
+    // the split whose busiest rank -- slice 0, the longest -- is estimated fastest; near-ties (3 %) go to more point slices: the ranks
+    // then hold less of the inputs
     double best = 1e300;
-    for (uint32_t w = 1; w <= world; ++w) {
-        if (world % w) continue;
-        const uint32_t p = world / w;
+    for (uint32_t p = world; p >= 1; --p) {
+        if (world % p) continue;
+        const uint32_t w = world / p;
         const uint32_t n_slice = (uint32_t)(((uint64_t)n + p - 1) / p);
-        if (p > 1 && n_slice < 4096) continue;   // slices this small are all fixed cost
-        const double t = shard_cost_ms(ctx, n_slice, nbits, w, group == 1, add_ns);
-        if (t < best * 0.97 || (t < best && w > *gw)) {   // (near-ties go to the split found first: fewer window groups, i.e. smaller inputs per rank)
+        if (p > 1 && n_slice < 1024) continue;   // slices this small are all fixed cost
+        const double t = shard_cost_ms(n_slice, w);
+        if (t < best * 0.97) {
             best = t;
             *gw = w;
             *gp = p;
@@ -211,17 +235,42 @@ __global__ void __launch_bounds__(256) k_table_next(const uint8_t* __restrict__ 
 
 // Window layout of a table for n points and scalars below 2^bits: `ns` signed windows of c bits followed by W - ns unsigned ones of
 // c - 1 bits (both kinds fill 2^(c-1) buckets evenly), the top one unsigned, W the fewest that cover `bits`, ns the fewest that do
-// it with W.  c minimises W x n bucket additions + the reduction of 2^(c-1) buckets (~6 additions' worth each, as pick_window_bits).
+// it with W.  The window size, measured (profiles/r03_sweep_prepared_window_bits.txt, BLS12-381 G1, ms per MSM with two calls in
+// flight, c | ms: n = 2^16  14 .636, 15 .617, 16 .602, 17 .648;  2^18  16 1.167, 17 .983, 18 .981, 19 1.099;  2^20  18 3.05, 19 3.01,
+// 20 2.55, 21 3.32;  2^22  19 11.4, 20 9.8, 21 10.5;  2^24  20 36.1, 21 38.7): c = log2 n up to 2^18, 20 from 2^19 on.  What decides is
+// not only W x n bucket additions against 2^(c-1) buckets to reduce: 2^18 buckets are 4096 accumulation waves, 1.33 rounds of the
+// 3072 that fit the chip, and the last third of a round costs almost a whole one (c = 19 at n = 2^20: 28 % more time per addition
+// than c = 20, whose 8192 waves are 2.67 rounds -- the same as the 16 x 2^15 buckets of the general path); 2^20 buckets (c = 21) hold
+// 13 entries each and the per-bucket costs show.  Below 2^16 the plain count decides: W x n additions + ~12 additions' worth per bucket.
 static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t* c_out, uint32_t* W_out, uint32_t* ns_out) {
-    uint64_t best = ~0ull;
-    *c_out = *W_out = *ns_out = 0;
-    for (uint32_t c = 3; c <= (uint32_t)MAX_WINDOW_BITS; ++c) {
-        if (forced_c && c != forced_c) continue;
+    auto layout = [&](uint32_t c, uint32_t* W, uint32_t* ns) {
         // W windows, ns of them signed (c bits), cover W (c - 1) + ns bits; ns <= W - 1 because the top window is unsigned
-        const uint32_t W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
-        const uint32_t ns = bits > W * (c - 1) ? bits - W * (c - 1) : 0u;
-        if ((uint64_t)W * n >= (1ull << 31)) continue;
-        const uint64_t cost = (uint64_t)W * n + 6ull * (1ull << (c - 1));
+        *W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
+        *ns = bits > *W * (c - 1) ? bits - *W * (c - 1) : 0u;
+        return (uint64_t)*W * n < (1ull << 31);
+    };
+    *c_out = *W_out = *ns_out = 0;
+    uint32_t want = forced_c;
+    if (!want && n >= (1u << 16)) {
+        uint32_t lg = 0;
+        while ((2ull << lg) <= n) ++lg;   // floor(log2 n)
+        want = n >= (1u << 19) ? 20u : lg;
+    }
+    if (want) {
+        // (a table too large for 31-bit entry indices at the wanted size takes the nearest wider window that fits)
+        for (uint32_t c = std::min<uint32_t>(want, MAX_WINDOW_BITS); c <= (uint32_t)MAX_WINDOW_BITS; ++c)
+            if (layout(c, W_out, ns_out)) {
+                *c_out = c;
+                return;
+            }
+        *W_out = *ns_out = 0;
+        return;
+    }
+    uint64_t best = ~0ull;
+    for (uint32_t c = 3; c <= 16u; ++c) {
+        uint32_t W, ns;
+        if (!layout(c, &W, &ns)) continue;
+        const uint64_t cost = (uint64_t)W * n + 12ull * (1ull << (c - 1));
         if (cost < best) {
             best = cost;
             *c_out = c;
@@ -310,6 +359,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
         return c;
     };
+    bool others_pending = false;
+    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
     bool small_est;
     {
         const uint32_t c0 = window_bits(), w0 = a.prepared ? 1u : a.nbits / c0 + 1;   // (prepared bases: one bucket set)
@@ -453,8 +504,6 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
     // reduction waves leave room for only one accumulation wave per SIMD, and two launches have two tails.  Kept for
     // experiments, off by default; overlapping across calls (slots) is what pays.
-    bool others_pending = false;
-    for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
     const bool split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
     const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
     const uint32_t split = w_split * g.half;                                               // first bucket of the second group
