@@ -116,10 +116,10 @@ def test_baseline_configs_at_full_size(eng, orc, curve, group, logn):
 def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     """The reference's g1m_multiexpAffine is integer arithmetic on curve points: exact for points outside the order-r subgroup too.
     The engine's GLV schedule (k mod r, endomorphism) is not -- so it only runs for callers that pass MSM_AMD_BASES_IN_SUBGROUP.
-    n = 100000 sits in the range (16-bit windows: 98304 <= n <= 2^18) where the GLV schedule is the default for flagged calls; a
-    smaller n = 4500 (8-bit windows, no GLV schedule whatever the flag says) is checked as well."""
+    n = 200000 sits in the range (180000 <= n <= 2^18) where the GLV schedule is the default for flagged calls (unflagged ones run 19
+    windows of 14 / 13 bits there); a smaller n = 4500 (8-bit windows, no GLV schedule whatever the flag says) is checked as well."""
     import msm_amd
-    curve, group, n = "bls12381", 1, 100000
+    curve, group, n = "bls12381", 1, 200000
     C = eng.curve(curve)
     O = orc.Oracle(curve, group)
     with open(os.path.join(gu.GOLDEN, "golden_ingroup.json")) as f:
@@ -138,7 +138,7 @@ def test_bases_outside_the_subgroup_match_the_reference(eng, orc):
     bases = bytes(bases)
     exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
     assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp               # default: no assumption about the bases
-    assert eng.geometry()["windows"] == 17
+    assert (eng.geometry()["c"], eng.geometry()["windows"]) == (14, 19)     # windows of even width: 9 of 14 bits, 10 of 13
     # flagged calls take the GLV schedule; with bases that really are in the subgroup it gives the reference's bytes
     good, gs = gu.random_case(curve, group, "gpu:cofactor:good", n)
     expg = O.normalize(O.multiexp_affine(good, gs, 32, n))
@@ -406,6 +406,10 @@ def _cabi_dist_rank(rank, world, q_id, q):
         else:
             uid = q_id.get(timeout=300)
         eng.dist_init(rank, world, uid)
+        import threading
+        eng.set_option("slots", 4)
+        ok = True
+        # (1) every rank holds everything (msm_amd_multiexp_dist): the split is planned per call -- points at this size
         curve, group, n = "bn128", 1, 6000
         C = eng.curve(curve)
         bases, scalars = gu.random_case(curve, group, "gpu:cabi-dist", n)
@@ -414,11 +418,51 @@ def _cabi_dist_rank(rank, world, q_id, q):
         r1 = C.multiexp_dist(group, d_b, d_s, 32, n)
         t = [C.multiexp_dist_async(group, d_b, d_s, 32, n) for _ in range(2)]
         r2, r3 = t[0].wait(), t[1].wait()
-        ok = r1 == r2 == r3
+        ok = ok and r1 == r2 == r3
+        # (2) every rank holds only ITS slice (msm_amd_dist_plan + msm_amd_multiexp_dist_local), both forced splits of two ranks
+        asz = C.affine_bytes(group)
+        for gw in (1, 2):
+            eng.set_option("dist_gw", gw)
+            plan = eng.dist_plan(curve, group, 32, n)
+            assert plan["gw"] == gw and plan["gp"] == world // gw
+            lb = bases[plan["first"] * asz:(plan["first"] + plan["count"]) * asz]
+            ls = scalars[plan["first"] * 32:(plan["first"] + plan["count"]) * 32]
+            ok = ok and C.multiexp_dist_local(group, lb, ls, 32, plan["count"], n) == r1
+        eng.set_option("dist_gw", 0)
+        # (3) a G1 and a G2 call in flight together, waited for from two threads in the opposite order: the exchanges still pair up
+        #     call by call on both ranks (submission order), 144-byte and 288-byte partials never meet
+        C2 = eng.curve("bls12381")
+        b1, s1 = gu.random_case("bls12381", 1, "gpu:cabi-dist:g1", 3000)
+        b2, s2 = gu.random_case("bls12381", 2, "gpu:cabi-dist:g2", 500)
+        tk = [C2.multiexp_dist_async(1, b1, s1, 32, 3000), C2.multiexp_dist_async(2, b2, s2, 32, 500), C2.multiexp_dist_async(1, b1, s1, 32, 3000)]
+        got = [None] * 3
+
+        def waiter(k):
+            got[k] = tk[k].wait()
+
+        th = [threading.Thread(target=waiter, args=(k,)) for k in (2, 1, 0)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join(timeout=300)
+        ok = ok and got[0] is not None and got[0] == got[2] and got[1] is not None
+        # (4) a rank whose part fails: rank 1 passes a slice length that contradicts the plan -- it gets its own error, rank 0 MSM_AMD_EPEER,
+        #     nobody hangs, and the next call is fine
+        plan = eng.dist_plan(curve, group, 32, n)
+        lb = bases[plan["first"] * asz:(plan["first"] + plan["count"]) * asz]
+        ls = scalars[plan["first"] * 32:(plan["first"] + plan["count"]) * 32]
+        try:
+            C.multiexp_dist_local(group, lb, ls, 32, plan["count"] - (1 if rank == 1 else 0), n)
+            ok = False
+        except msm_amd.MsmAmdError as e:
+            ok = ok and e.code == (msm_amd.EINVAL if rank == 1 else msm_amd.EPEER)
+        ok = ok and C.multiexp_dist_local(group, lb, ls, 32, plan["count"], n) == r1
         if rank == 0:
             orcm.build()
             O = orcm.Oracle(curve, group)
             ok = ok and r1 == O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+            O1, O2 = orcm.Oracle("bls12381", 1), orcm.Oracle("bls12381", 2)
+            ok = ok and got[0] == O1.normalize(O1.multiexp_affine(b1, s1, 32, 3000)) and got[1] == O2.normalize(O2.multiexp_affine(b2, s2, 32, 500))
         q.put((rank, ok, r1.hex()[:16]))
     finally:
         eng.close()
@@ -426,7 +470,10 @@ def _cabi_dist_rank(rank, world, q_id, q):
 
 def test_two_ranks_through_the_c_entry_points():
     """The same two-GPU exchange with nothing but the C ABI in the data path: msm_amd_dist_unique_id on rank 0, msm_amd_dist_init on
-    both, msm_amd_multiexp_dist[_async] -- what a Node host reaches through the addon's distInit / multiexpDist."""
+    both, msm_amd_multiexp_dist[_async] -- what a Node host reaches through the addon's distInit / multiexpDist -- then the hybrid form
+    with slice-local inputs (msm_amd_dist_plan / msm_amd_multiexp_dist_local, both splits of two ranks), a G1 and a G2 call in flight
+    waited for in the opposite order from two threads, and a call that fails on one rank only (that rank: its own error; the other:
+    MSM_AMD_EPEER; the group goes on)."""
     import torch
     import torch.multiprocessing as mp
     if torch.cuda.device_count() < 2:

@@ -278,7 +278,7 @@ def test_prepared_bases_match_oracle_for_every_window_layout(eng, orc, curve, gr
                     assert info["c"] == c
                 bits = 255 if curve == "bls12381" else 254
                 assert info["scalar_bits"] == bits and info["windows"] * (info["c"] - 1) + info["signed_windows"] >= bits
-                assert info["signed_windows"] < info["windows"] and info["table_bytes"] == info["windows"] * n * asz
+                assert info["signed_windows"] < info["windows"] and info["table_bytes"] == info["windows"] * ((n + 4095) // 4096 * 4096) * asz
                 eng.set_window_bits(0)                       # the call takes its layout from the table, not from the option
                 assert pb.multiexp(scalars) == exp, c
                 g = eng.geometry()
@@ -390,4 +390,44 @@ def test_prepared_bases_at_the_headline_size(eng, orc):
         assert pb.multiexp(sc, 32, m) == O.normalize(O.multiexp_affine(h_pts, h_sc, 32, m))
     finally:
         pb.release()
+        pts.free()
+
+
+def test_index_slices_of_the_partition(eng, orc):
+    """4-byte partition entries at every size: indices wider than the entry's index field put their high bits into the bin (S sub-bins
+    per (window, coarse bin), csrc/sort_kernels.hpp SortGeom).  With 21-bit windows the field is 19 bits, with 20-bit ones 20: n = 700 001
+    points are 2 slices there (the BASELINE sizes reach the same paths at 16-bit windows from n = 2^23: test_gpu_configs).  Every form of
+    the fine sort -- chunk-parallel kernels, one workgroup per span chunk by chunk, short spans held in registers (the dense low bins of
+    a narrow top window aside, spans at this size are short at c = 21) -- must reproduce the result of the plain 16-bit schedule, which
+    the oracle pins on a slice of the same inputs."""
+    import torch
+    curve, group, n = "bls12381", 1, 700001
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    pts = C.gen_points(group, 0x51CE5, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4242)
+    sc = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    sc[:, 31] &= 0x7F
+    torch.cuda.synchronize()
+    try:
+        m = 2500
+        assert C._multiexp(group, 0, pts, sc, 32, m) == O.normalize(O.multiexp_affine(pts.download(m * 96), sc[:m].cpu().numpy().tobytes(), 32, m))
+        ref = C._multiexp(group, 0, pts, sc, 32, n)
+        assert eng.geometry()["c"] == 16
+        for c in (21, 20, 18):
+            eng.set_window_bits(c)
+            for big in (0, 1, 2):
+                eng.set_option("sort_big", big)
+                assert C._multiexp(group, 0, pts, sc, 32, n) == ref, (c, big)
+            # a window shard and two calls in flight on the sliced partition
+            eng.set_option("sort_big", 0)
+            import msm_amd
+            parts = b"".join(C.multiexp_shard(group, pts, sc, 32, n, r, 3) for r in range(3))
+            assert msm_amd.combine(curve, group, parts) == ref, c
+            t1, t2 = C.multiexp_async(group, pts, sc, 32, n), C.multiexp_async(group, pts, sc, 32, n)
+            assert t1.wait() == ref and t2.wait() == ref
+    finally:
+        eng.set_window_bits(0)
+        eng.set_option("sort_big", 0)
         pts.free()

@@ -37,7 +37,21 @@ def one_pass(counter, bench_args, tag):
         s = acc.setdefault(name, [0, 0.0])
         s[0] += 1
         s[1] += float(r["Counter_Value"])
+    # launch durations of the same pass (kernel trace)
+    dur = {}
+    for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            try:
+                d = dur.setdefault(r["Kernel_Name"], [0, 0.0])
+                d[0] += 1
+                d[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
+    DUR.update({k: v[1] / v[0] for k, v in dur.items()})
     return {k: (v[0], v[1] / v[0]) for k, v in acc.items()}
+
+
+DUR = {}   # kernel -> mean launch duration in ns (of the last pass that saw it)
 
 
 def short(name):
@@ -59,6 +73,10 @@ def main():
         _, w = write.get(k, (0, 0.0))
         res[short(k)] = {"launches": n, "FETCH_SIZE_KB_raw": round(f, 2), "WRITE_SIZE_KB": round(w, 2),
                          "hbm_MB_fetch_x2": round((2 * f + w) * 1024 / 1e6, 2), "hbm_MB_fetch_x1": round((f + w) * 1024 / 1e6, 2)}
+        if DUR.get(k):
+            us = DUR[k] / 1e3
+            res[short(k)]["avg_us"] = round(us, 2)
+            res[short(k)]["GBps_on_moved_bytes_fetch_x2"] = round((2 * f + w) * 1024 / (us * 1e-6) / 1e9, 1)
     doc = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --no-cpu-baseline --no-pipeline " + " ".join(bench_args),
            "units": "mean per launch; KB as rocprofv3 reports (x1024 bytes); MB = 1e6 bytes",
            "kernels": res}

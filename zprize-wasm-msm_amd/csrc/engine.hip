@@ -70,7 +70,7 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
 }
 
-static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below) {
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below, bool even = true) {
     uint32_t c;
     if (forced) {
         c = forced;
@@ -93,8 +93,9 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
             // a top window of fewer than 12 bits (c = 19 over 256 bits: 9) has a few hundred buckets of n / 2^tb entries each, which go
             // through the tail kernels at half the efficiency: count it twice (n = 2^24, ms per MSM at c = 19 | 20: BN254 20.8 | 20.2,
             // BLS12-381 40.5 | 37.8 -- k_accumulate_tail + k_combine_tail took 2.6 of BN254's 20.8)
+            // (with windows of even width -- submit_msm -- there is no such top window)
             const uint32_t tb = nbits - (w - 1) * cand;
-            if (tb < 12 && tb < cand) cost += n;
+            if (!even && tb < 12 && tb < cand) cost += n;
             if (cost < best) {
                 best = cost;
                 c = cand;
@@ -110,8 +111,13 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
         // 2^16 1.73 | 1.75, 2^17 2.74 | 2.15; BN254 G2 2^14 0.48 | 0.89, 2^16 0.77 | 0.93, 2^17 1.31 | 1.06): narrow_below = 98304 for
         // G1, 65537 for G2.  Widths between 9 and 15 lose to both: 256 is not a multiple of them and the few dense buckets of their
         // narrow top window set the duration of the accumulation.
+        // With windows of even width (submit_msm) the sizes in between are usable: 14 bits -- 19 windows of 14 / 13 bits over 2^13
+        // buckets each -- from n = 49152 up to 2^18 for G1 (profiles/r03_even_windows_and_slices.txt, ms per MSM at c = 8 | 12 | 14 | 16:
+        // n = 2^16 .790 | .740 | .736 | 1.036, 2^17 1.103 | .991 | .862 | 1.105, 2^18 1.820 | 1.585 | 1.264 | 1.288; below, 8 bits stay
+        // ahead: 2^14 .488 | .577 | .639 | .983).  G2 and sharded calls keep the round-2 rule.
         const uint32_t wide_from = nshards == 1 ? narrow_below : 4096u;
         c = n >= wide_from ? 16 : 8;
+        if (even && nshards == 1 && narrow_below == 98304u && n >= 49152u && n < (1u << 18)) c = 14;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
@@ -247,7 +253,7 @@ static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t
         // W windows, ns of them signed (c bits), cover W (c - 1) + ns bits; ns <= W - 1 because the top window is unsigned
         *W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
         *ns = bits > *W * (c - 1) ? bits - *W * (c - 1) : 0u;
-        return (uint64_t)*W * n < (1ull << 31);
+        return (uint64_t)*W * (((uint64_t)n + 4095u) & ~4095ull) < (1ull << 31);   // (table rows are padded to 4096 points)
     };
     *c_out = *W_out = *ns_out = 0;
     uint32_t want = forced_c;
@@ -285,7 +291,9 @@ static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, ui
     const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
     const uint32_t n = h->n;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    h->table_bytes = (size_t)h->W * n * ASZ;
+    h->stride = (n + 4095u) & ~4095u;
+    const size_t row = (size_t)h->stride * ASZ;
+    h->table_bytes = (size_t)h->W * row;
     HIPCHK(ctx, hipMalloc(&h->table, h->table_bytes));
     hipStream_t st = ctx->stream_s;
     uint8_t* t0 = (uint8_t*)h->table;
@@ -312,7 +320,7 @@ static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, ui
     g.ns = h->ns;
     for (uint32_t w = 1; w < h->W; ++w) {
         const uint32_t ndbl = window_start_bit(g, w) - window_start_bit(g, w - 1);
-        k_table_next<F><<<((n + 3) / 4 + 255) / 256, 256, 0, st>>>(t0 + (size_t)(w - 1) * n * ASZ, n, ndbl, t0 + (size_t)w * n * ASZ);
+        k_table_next<F><<<((n + 3) / 4 + 255) / 256, 256, 0, st>>>(t0 + (size_t)(w - 1) * row, n, ndbl, t0 + (size_t)w * row);
     }
     HIPCHK(ctx, hipStreamSynchronize(st));
     HIPCHK(ctx, hipGetLastError());
@@ -354,9 +362,15 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // applies, and that schedule is built on 16-bit windows
     auto window_bits = [&]() -> uint32_t {
         if (a.prepared) return a.prepared->c;   // the table fixes the window layout
-        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (KernelField<F>::chained_variant ? 98304u : 65537u));
-        if constexpr (GlvField<F>::value)
+        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (KernelField<F>::chained_variant ? 98304u : 65537u), ctx->even_windows != 0);
+        if constexpr (GlvField<F>::value) {
             if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
+            // bases vouched to lie in the subgroup: from n ~ 180 000 the GLV schedule (8 windows of 16 bits over 2n half scalars) is ahead
+            // of the 14-bit windows chosen below 2^18 (n = 2^17: 0.94 against 0.86 ms, 2^18: 1.15 against 1.26)
+            if (!ctx->force_c && ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP) && a.nshards == 1 && a.n >= 180000u && a.n <= (1u << 18) &&
+                a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256)
+                c = 16;
+        }
         return c;
     };
     bool others_pending = false;
@@ -412,11 +426,22 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     g.ns = g.W;
     g.merged = 0;
     g.stride = 0;
+    // Windows of even width.  With nbits / c + 1 windows of c bits the top one holds nbits % c bits: when that is neither 0 nor the full
+    // width, its 2^(nbits % c) buckets are 2^(c - 1 - nbits % c) times as dense as all the others (c = 13 over 256 bits: 256 buckets of
+    // n / 256 entries each) and their lanes set the duration of the accumulation -- which is why round 2 found no window size between
+    // 9 and 15 bits worth using.  Instead: W = ceil((nbits + 1) / c) windows, the first ns of them c bits wide and signed, the rest
+    // c - 1 bits wide and unsigned (no carry out of the top one), ns chosen so that they tile the nbits exactly -- both kinds fill their
+    // 2^(c-1) buckets evenly (the layout of the prepared tables, Geom in engine_common.hpp).  Kept for nbits % c == 0 is the old
+    // layout: its top window is full, and the carry-only window above it stays empty for scalars whose top bit is clear.
+    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits % g.c != 0 && g.nbits > g.c) {
+        g.W = (g.nbits + g.c) / g.c;
+        g.ns = g.nbits > g.W * (g.c - 1) ? g.nbits - g.W * (g.c - 1) : 0u;
+    }
     if (a.prepared) {   // the table's windows: ns signed of c bits, the rest unsigned of c - 1; all into ONE bucket set
         g.W = a.prepared->W;
         g.ns = a.prepared->ns;
         g.merged = 1;
-        g.stride = a.prepared->n;
+        g.stride = a.prepared->stride;
     }
     // GLV path -- only for callers that vouch for their bases (flag MSM_AMD_BASES_IN_SUBGROUP, or option "glv" = 2): k*P = k1*P + k2*phi(P)
     // with k reduced mod r holds in the order-r subgroup only, while the reference's multiexp is plain integer arithmetic, exact for
@@ -516,9 +541,20 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         sg.cbits = g.c - 1 - sg.fbits;
         sg.cb = 1u << sg.cbits;
         sg.nbins = g.Wl * sg.cb;
+        // 4-byte partition entries {fine key | sign | index} at every size: the index field takes what the fine key and the sign leave
+        // of 32 bits; wider indices (n > 2^23 at c = 16, the W x n table indices of prepared bases) put their HIGH bits into the bin --
+        // S sub-bins per (window, coarse bin), see SortGeom
+        const uint64_t max_index = g.merged ? (uint64_t)g.W * g.stride : (uint64_t)nv;
         sg.idxbits = 1;
-        while ((1ull << sg.idxbits) < (g.merged ? (uint64_t)g.W * g.stride : (uint64_t)nv)) ++sg.idxbits;
-        const bool e32 = sg.fbits + 1 + sg.idxbits <= 32;     // 4-byte partition entries {fine key | sign | index}
+        while ((1ull << sg.idxbits) < max_index) ++sg.idxbits;
+        sg.idxbits = std::min(sg.idxbits, 31u - sg.fbits);
+        sg.S = (uint32_t)((max_index + (1ull << sg.idxbits) - 1) >> sg.idxbits);
+        if (sg.S == 0) sg.S = 1;
+        if (sg.S > 2048u) {
+            msm_set_err(ctx, "too many points for one pass of the sort (index slices > 2048): fewer points per call");
+            return MSM_AMD_EINVAL;
+        }
+        const size_t nsub = (size_t)sg.nbins * sg.S;   // bins the partition scatters into
         // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
         // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
         // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
@@ -530,12 +566,12 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
         const size_t max_chunks = ((size_t)g.Wl * nve) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
-        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * (e32 ? 4 : 8))) return rc;
+        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * 4)) return rc;
         // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
         // well, ZeroMark in engine_ctx.hpp)
-        if (int rc = ensure(ctx, sl->d_binhist, (size_t)sg.nbins * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_binstart, ((size_t)sg.nbins + 1) * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_bincur, (size_t)sg.nbins * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_binhist, nsub * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_binstart, (nsub + 1) * 4)) return rc;
+        if (int rc = ensure(ctx, sl->d_bincur, nsub * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
         if (int rc = ensure(ctx, sl->d_desc, max_chunks * 8)) return rc;
         if (int rc = ensure(ctx, sl->d_bcursor, (size_t)NB * 4)) return rc;
@@ -557,7 +593,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         } else if (a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && (((uintptr_t)d_scalars & 15) == 0)) {
             nw = 8;
         }
-        const size_t hist_lds = (size_t)sg.nbins * 4;
+        const size_t hist_lds = (size_t)(g.merged ? g.W : g.Wl) * sg.cb * 4;   // one row per window
         if (hist_lds > 64 * 1024) {
             msm_set_err(ctx, "too many windows x coarse bins for the histogram kernel (use a wider window)");
             return MSM_AMD_EINVAL;
@@ -579,7 +615,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 #undef MSM_TILE_HIST
         HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
         // ---- 2. bin starts
-        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
+        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, sg.S, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
         sl->binhist_zero.set(sl->d_binhist);
         HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
         // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
@@ -595,8 +631,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     } while (0)
 #define MSM_TILE_SCATTER_E(NW, BL)          \
     do {                                    \
-        if (e32) MSM_TILE_SCATTER(NW, BL, uint32_t, 4); \
-        else MSM_TILE_SCATTER(NW, BL, uint2, 2);        \
+        MSM_TILE_SCATTER(NW, BL, uint32_t, 4);          \
     } while (0)
         if (wide) {
             if (nw == 8) MSM_TILE_SCATTER_E(8, 1024);
@@ -610,44 +645,35 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 #undef MSM_TILE_SCATTER_E
 #undef MSM_TILE_SCATTER
         const uint32_t nf = 1u << sg.fbits;
-        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * BIG_CHUNK) * 4;
+        const size_t bnd_lds = sg.S > 1 ? ((size_t)sg.S + 1) * 4 : 0;   // sub-bin boundaries of one span
+        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * BIG_CHUNK) * 4 + bnd_lds;
         // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
         // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
         // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
         // (a prepared table's windows all fill the bucket set evenly: no partly used top window)
-        const uint32_t tb = g.merged ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
+        const uint32_t tb = (g.merged || g.ns != g.W) ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
         const uint64_t mean_span = (uint64_t)nve / sg.cb;
         const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
         if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
         }
         if (!expect_long || ctx->sort_big == 2) {
-            if (e32) k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-            else k_fine_small<uint2, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+            k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
         } else {
             if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
                 HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
             }
             const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
             HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
-            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, cpre);
-            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, desc);
-            if (e32) {
-                k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-                k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
-            } else {
-                k_fine_small<uint2, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-                k_big_hist<uint2><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
-            }
+            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, cpre);
+            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, desc);
+            k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+            k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
             k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
             // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
             const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
-            if (e32) k_big_scatter<uint32_t><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
-            else k_big_scatter<uint2><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint2*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            k_big_scatter<uint32_t><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
         }
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
@@ -689,7 +715,8 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     };
     // segments are expected for the tail kernels when recent calls queued some (skewed scalars), when the segment length is forced,
     // and when the top window is only partly filled (few, dense buckets; the last rank of a 254-bit field)
-    const bool tail_expected = ctx->skew_hint.load() > 0 || ctx->force_seg != 0 || (!g.merged && (g.nbits % g.c) != 0);
+    const bool even_layout = g.merged || g.ns != g.W;   // every window fills its buckets evenly: no partly used top window
+    const bool tail_expected = ctx->skew_hint.load() > 0 || ctx->force_seg != 0 || (!even_layout && (g.nbits % g.c) != 0);
     const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
     const bool small_acc = ctx->acc_stream ? ctx->acc_stream == 1 : (NB < 5u * 1024u * 64u && !split_mode);
     st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
@@ -713,7 +740,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // as long as their chain stays below the launch's own duration (cap: 80 % of a lane slot's share of the additions).
         auto bound = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d + 8u * (uint64_t)std::ceil(std::sqrt((double)d)) + 8u, 1u << 24); };
         uint32_t seg_hi = bound(2ull * mean);
-        const uint32_t tb = g.merged ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
+        const uint32_t tb = even_layout ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
         if (tb >= 12 && tb < g.c - 1) seg_hi = std::max(seg_hi, bound(2ull * (((uint64_t)nv + (1ull << tb) - 1) >> tb)));
         const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nve) / 245760u, 1u << 20);
         seg = std::max(seg, std::min(seg_hi, cap));
@@ -896,13 +923,13 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
         int wglob = g.merged ? 0 : wl * (int)g.nshards + (int)g.shard;   // (prepared table: the window weights are in the table)
         if (prev_w >= 0)
-            for (int k = 0; k < (prev_w - wglob) * (int)g.c; ++k) total = HX::dbl(total);
+            for (int k = 0; k < (int)(window_start_bit(g, (uint32_t)prev_w) - window_start_bit(g, (uint32_t)wglob)); ++k) total = HX::dbl(total);
         HX s = HX::inf();
         for (uint32_t k = 0; k < sl->part_cnt[wl]; ++k) s = HX::add(s, parts[(size_t)sl->part_off[wl] + k]);
         total = HX::add(total, s);
         prev_w = wglob;
     }
-    for (int k = 0; k < prev_w * (int)g.c; ++k) total = HX::dbl(total);
+    for (int k = 0; prev_w > 0 && k < (int)window_start_bit(g, (uint32_t)prev_w); ++k) total = HX::dbl(total);
     if (sl->raw_out) host_store_jacobian_raw(total, out);
     else host_store_jacobian_normalised(total, out);
     auto t1 = std::chrono::steady_clock::now();
@@ -1309,6 +1336,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
     if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size
     if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A

@@ -94,9 +94,10 @@ struct msm_amd_bases {
     msm_amd_ctx* ctx = nullptr;
     int curve = 0, group = 0;
     uint32_t n = 0;             // points
+    uint32_t stride = 0;        // points per table row: n rounded up to the sort's largest tile (4096), so that a tile of scalars never straddles an index slice
     uint32_t scalar_bits = 0;   // the windows cover scalars below 2^scalar_bits
     uint32_t c = 0, W = 0, ns = 0;   // window layout (Geom: ns windows of c bits, signed, then W - ns of c - 1 bits, unsigned)
-    void* table = nullptr;      // [W][n] affine points, the reference's packed Montgomery image: table[w][i] = 2^(start bit of window w) * P_i
+    void* table = nullptr;      // [W][stride] affine points, the reference's packed Montgomery image: table[w][i] = 2^(start bit of window w) * P_i
     size_t table_bytes = 0;
     std::atomic<int> in_flight{0};   // calls submitted and not yet collected (release refuses while > 0)
 };
@@ -126,6 +127,7 @@ struct msm_amd_ctx {
     } dist;
     std::mutex dist_mu;
     std::condition_variable dist_cv;   // next_exchange moved on
+    int even_windows = 1;              // option "even_windows": windows of c and c - 1 bits that tile the scalar exactly when c does not divide its width
     uint32_t dist_gw = 0;              // option "dist_gw": window groups of a sharded call (0 = chosen per call; must divide the world size)
     // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are
     // serialised by `mu`; WAITING for the GPU happens outside it, so calls issued from different threads -- e.g. the libuv

@@ -169,9 +169,29 @@ struct GlvField<Fp<Bls12381Fp>> {
 struct SortGeom {
     uint32_t cbits, fbits;   // c - 1 = cbits + fbits; cbits <= 8, fbits <= 12
     uint32_t cb;             // coarse bins per window = 2^cbits
-    uint32_t nbins;          // owned windows x coarse bins
-    uint32_t idxbits;        // bits of an item index (4-byte entries: fine key above the sign bit at position idxbits)
+    uint32_t nbins;          // owned windows x coarse bins ("parent" bins: one span of the fine sort each)
+    uint32_t idxbits;        // bits of the index field of a 4-byte entry {fine key | sign | index}: fine key above the sign bit at position idxbits
+    // Indices wider than idxbits (n > 2^23 at c = 16, > 2^20 at c = 20; the W x n table indices of prepared bases): every parent bin
+    // is cut into S sub-bins by the HIGH bits of the index -- sub-bin s holds the entries with index >> idxbits == s, in the order
+    // s = 0, 1, ... inside the parent's span -- and an entry keeps the low idxbits only.  The position of an entry in its parent's
+    // span says which sub-bin it is in, so the fine sort puts the high bits back.  A tile of scalars lies in ONE slice of the index
+    // space (2^idxbits is a multiple of the tile size), so the partition kernels know s per (tile, window) and keep one reservation
+    // per run.  S = 1: plain entries, as before.  Entries stay 4 bytes at every size (round 2 switched to 8 bytes there: twice the
+    // partition traffic, three passes over it).
+    uint32_t S;
 };
+MSM_D uint32_t slice_of_index(const SortGeom& sg, uint32_t index) { return sg.S > 1 ? index >> sg.idxbits : 0u; }
+// sub-bin of the entry at position p of a parent span whose S + 1 sub-bin boundaries are bnd[0..S] (non-decreasing, absolute positions;
+// empty sub-bins repeat a value): the largest k < S with bnd[k] <= p
+MSM_D uint32_t slice_of_position(const uint32_t* bnd, uint32_t S, uint32_t p) {
+    uint32_t lo = 0, hi = S;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (bnd[mid] <= p) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
 
 // ------------------------------------------------------------------------------------------
 // k_tile_hist: binhist[wl * cb + bin] += entries of this tile that fall into (owned window wl, coarse bin)
@@ -181,15 +201,18 @@ template <int NW, int ITEMS, int BLOCK>
 __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ binhist,
                                                       uint32_t* __restrict__ too_wide) {
     extern __shared__ uint32_t smem_u32[];
-    uint32_t* h = smem_u32;   // [Wl][cb]
+    // [rows][cb]: one row per owned window -- per window of a prepared table, whose windows share the parent bins but not the slice
+    // of the index space their entries fall into
+    uint32_t* h = smem_u32;
     const uint32_t tile = blockIdx.x;
-    for (uint32_t s = threadIdx.x; s < sg.nbins; s += BLOCK) h[s] = 0;
+    const uint32_t rows = g.merged ? g.W : g.Wl, nh = rows * sg.cb;
+    for (uint32_t s = threadIdx.x; s < nh; s += BLOCK) h[s] = 0;
     __syncthreads();
     DigitSource<NW, ITEMS, BLOCK> ds;
     ds.load(scalars, g, tile * (ITEMS * BLOCK));
     for (uint32_t w = 0; w < g.W; ++w) {
         const bool owned = g.merged || (w % g.nshards) == g.shard;
-        const uint32_t wl = g.merged ? 0u : w / g.nshards;
+        const uint32_t wl = g.merged ? w : w / g.nshards;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) {
             uint32_t mag;
@@ -205,44 +228,56 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
         if (wide) atomicOr(too_wide, 1u);
     }
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < sg.nbins; s += BLOCK) {
+    for (uint32_t s = threadIdx.x; s < nh; s += BLOCK) {
         const uint32_t v = h[s];
-        if (v) atomicAdd(&binhist[s], v);
+        if (v) {
+            const uint32_t row = s / sg.cb, bin = s % sg.cb;
+            const uint32_t parent = g.merged ? bin : row * sg.cb + bin;
+            const uint32_t slice = slice_of_index(sg, (g.merged ? row * g.stride : 0u) + tile * (ITEMS * BLOCK));
+            // (slice-major: the tiles of one slice share nbins consecutive counters -- a few dozen cache lines, as without slices;
+            // parent-major put every counter of a tile on a line of its own and the pass took 3.5 times as long at n = 2^26)
+            atomicAdd(&binhist[slice * sg.nbins + parent], v);
+        }
     }
 }
 
-// single workgroup: binstart[k] = exclusive scan of binhist (binstart[nbins] = total), cursor[k] = binstart[k].  It also leaves
-// binhist zeroed for the slot's next call and zeroes the key counters of the population ordering (two fill launches less).
-__global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* __restrict__ binhist, uint32_t nbins, uint32_t* __restrict__ binstart,
+// single workgroup: the exclusive scan of the bin populations.  Positions run over the bins in parent-major order -- all sub-bins
+// (index slices) of a parent bin one after the other, so that a parent's span is contiguous: binstart[parent * S + slice], with
+// binstart[nparent * S] = total -- while the counters the tiles add to (binhist) and reserve from (cursor) are kept slice-major,
+// [slice][parent]: the tiles of one slice then share a few dozen cache lines.  Leaves binhist zeroed for the slot's next call and
+// zeroes the key counters of the population ordering (two fill launches less).
+__global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* __restrict__ binhist, uint32_t nparent, uint32_t S, uint32_t* __restrict__ binstart,
                                                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ order_bins, uint32_t n_order_bins) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
-    const uint32_t t = threadIdx.x;
-    if (t == 0) carry_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < nbins; base += 1024) {
-        const uint32_t i = base + t;
-        const uint32_t v = i < nbins ? binhist[i] : 0u;
-        uint32_t incl = v;
+    const uint32_t t = threadIdx.x, nbins = nparent * S;
+    // lane t owns the `per` consecutive (parent-major) bins from t * per: their sum, a block-wide exclusive scan of the 1024 sums, then
+    // the positions.  (One pass of 1024 bins per iteration with two barriers each took 0.47 ms for the 213 000 bins of n = 2^26.)
+    const uint32_t per = (nbins + 1023u) / 1024u, lo = min(t * per, nbins), hi = min(lo + per, nbins);
+    auto src_of = [&](uint32_t i) { return S > 1 ? (i % S) * nparent + i / S : i; };   // the same bin, slice-major
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += binhist[src_of(i)];
+    uint32_t incl = sum;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(incl, d, 64);
-            if ((int)(t & 63u) >= d) incl += o;
-        }
-        if ((t & 63u) == 63u) wsum[t >> 6] = incl;
-        __syncthreads();
-        uint32_t run = carry_s + incl - v;
-        for (uint32_t q = 0; q < (t >> 6); ++q) run += wsum[q];
-        if (i < nbins) {
-            binstart[i] = run;
-            cursor[i] = run;
-            binhist[i] = 0;
-        }
-        __syncthreads();
-        if (t == 1023) carry_s = run + v;
-        __syncthreads();
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(t & 63u) >= d) incl += o;
     }
-    if (t == 0) binstart[nbins] = carry_s;
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q) {
+        if (q < (t >> 6)) run += wsum[q];
+        total += wsum[q];
+    }
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t src = src_of(i), v = binhist[src];
+        binstart[i] = run;
+        cursor[src] = run;
+        binhist[src] = 0;
+        run += v;
+    }
+    if (t == 0) binstart[nbins] = total;
     for (uint32_t i = t; i < n_order_bins; i += 1024) order_bins[i] = 0;
 }
 
@@ -358,7 +393,9 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
         // every non-empty run reserves its span of the bin
         for (uint32_t s = t; s < ncnt; s += BLOCK) {
             const uint32_t w = w0 + s / sg.cb, bin = s % sg.cb, cnt = hs[s];
-            gb[s] = cnt ? atomicAdd(&cursor[(g.merged ? 0u : w / g.nshards) * sg.cb + bin], cnt) : 0u;   // cnt != 0 only for owned windows
+            // (cnt != 0 only for owned windows; the run's sub-bin: the slice of the index space this tile's entries of window w lie in)
+            const uint32_t parent = (g.merged ? 0u : w / g.nshards) * sg.cb + bin;
+            gb[s] = cnt ? atomicAdd(&cursor[slice_of_index(sg, (g.merged ? w * g.stride : 0u) + tile * T) * sg.nbins + parent], cnt) : 0u;   // (slice-major, like binhist)
         }
         const uint32_t staged = block_exclusive_scan<BLOCK>(hs, ncnt, wsum);   // hs: start of each run inside the staged group
 #pragma unroll
@@ -368,7 +405,8 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
                 if ((livem[gw] >> k) & 1u) {
                     const uint32_t b = mr[gw][k] >> 12, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
                     // (prepared bases: the entry addresses the table point of this window, w * stride + i)
-                    stage[slot] = make_entry<E>((g.merged ? (w0 + gw) * g.stride : 0u) + ds.first + k * BLOCK, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
+                    const uint32_t index = (g.merged ? (w0 + gw) * g.stride : 0u) + ds.first + k * BLOCK;
+                    stage[slot] = make_entry<E>(sg.S > 1 ? index & ((1u << sg.idxbits) - 1u) : index, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
                     srun[slot] = (uint16_t)run;
                 }
             }
@@ -414,8 +452,17 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
     uint32_t* out = smem_u32 + 2 * nf;      // [FINE_CAP] the span (or one chunk of it), grouped by bucket
     __shared__ uint32_t wsum[SORT_BLOCK / 64];
     const uint32_t bin = blockIdx.x;                              // = wl * cb + coarse bin
-    const uint32_t start = binstart[bin], end = binstart[bin + 1];
+    const uint32_t start = binstart[bin * sg.S], end = binstart[(bin + 1) * sg.S];
     const uint32_t span = end - start, t = threadIdx.x;
+    // sub-bin boundaries of this span (S > 1: the entries keep the low bits of their index, the sub-bin is the rest)
+    uint32_t* bnd = smem_u32 + 2 * nf + FINE_CAP;                 // [S + 1]
+    if (sg.S > 1) {
+        for (uint32_t i = t; i <= sg.S; i += SORT_BLOCK) bnd[i] = binstart[bin * sg.S + i];
+        __syncthreads();
+    }
+    auto high_bits = [&](uint32_t pos) -> uint32_t {              // of the entry at position `pos` of the span
+        return sg.S > 1 ? slice_of_position(bnd, sg.S, start + pos) << sg.idxbits : 0u;
+    };
     const uint32_t wl = bin / sg.cb, cbin = bin % sg.cb;
     const uint32_t gb0 = wl * half + (cbin << sg.fbits);
     if (span > (uint32_t)FINE_CAP) {
@@ -438,7 +485,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
                     const E e = tmp[cbeg + s];
                     const uint32_t f = entry_fine(e, sg.idxbits);
                     const uint32_t r = atomicAdd(&th[f], 1u);
-                    sorted[start + h[f] + r] = entry_sorted(e, sg.idxbits);   // h is not modified during this loop
+                    sorted[start + h[f] + r] = entry_sorted(e, sg.idxbits) + high_bits(cbeg - start + s);   // h is not modified during this loop
                 }
                 __syncthreads();
                 for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] += th[i];
@@ -511,7 +558,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
     for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
 #pragma unroll
     for (int k = 0; k < FINE_ITEMS; ++k)
-        if (slot_of(k) != 0xffffffffu) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits);
+        if (slot_of(k) != 0xffffffffu) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits) + high_bits(slot_of(k));
     __syncthreads();
     if constexpr (VEC) {
         uint4* op = reinterpret_cast<uint4*>(sorted + start + head);
@@ -537,7 +584,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
 constexpr int BIG_ITEMS = 32;
 constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries (16384 were tried: no faster at n = 2^26, and 164 KB of LDS at 12 fine bits)
 
-__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t* __restrict__ cpre) {
+__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t S, uint32_t* __restrict__ cpre) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t t = threadIdx.x;
@@ -547,7 +594,7 @@ __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ 
         const uint32_t i = base + t;
         uint32_t v = 0;
         if (i < nbins) {
-            const uint32_t span = binstart[i + 1] - binstart[i];
+            const uint32_t span = binstart[(i + 1) * S] - binstart[i * S];
             v = span > (uint32_t)FINE_CAP ? (span + BIG_CHUNK - 1) / BIG_CHUNK : 0u;
         }
         uint32_t incl = v;
@@ -567,7 +614,7 @@ __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ 
     }
     if (t == 0) cpre[nbins] = carry_s;
 }
-__global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre, uint32_t nbins,
+__global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre, uint32_t nbins, uint32_t S,
                                                    uint2* __restrict__ desc) {
     const uint32_t total = cpre[nbins];
     for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
@@ -577,7 +624,7 @@ __global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ b
             if (cpre[mid] <= it) lo = mid;
             else hi = mid;
         }
-        desc[it] = make_uint2(lo, binstart[lo] + (it - cpre[lo]) * BIG_CHUNK);
+        desc[it] = make_uint2(lo, binstart[lo * S] + (it - cpre[lo]) * BIG_CHUNK);
     }
 }
 template <class E>
@@ -588,7 +635,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_hist(const E* __restrict__ t
     const uint32_t nf = 1u << sg.fbits, total = cpre[sg.nbins], t = threadIdx.x;
     for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
         const uint2 d = desc[it];
-        const uint32_t end = min(binstart[d.x + 1], d.y + BIG_CHUNK);
+        const uint32_t end = min(binstart[(d.x + 1) * sg.S], d.y + BIG_CHUNK);
         for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
         __syncthreads();
         for (uint32_t p = d.y + t; p < end; p += SORT_BLOCK) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
@@ -606,8 +653,8 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __re
     extern __shared__ uint32_t smem_u32[];
     uint32_t* h = smem_u32;   // [nf]
     __shared__ uint32_t wsum[SORT_BLOCK / 64];
-    const uint32_t bin = blockIdx.x, start = binstart[bin], t = threadIdx.x, nf = 1u << sg.fbits;
-    if (binstart[bin + 1] - start <= (uint32_t)FINE_CAP) return;
+    const uint32_t bin = blockIdx.x, start = binstart[bin * sg.S], t = threadIdx.x, nf = 1u << sg.fbits;
+    if (binstart[(bin + 1) * sg.S] - start <= (uint32_t)FINE_CAP) return;
     const uint32_t gb0 = (bin / sg.cb) * half + ((bin % sg.cb) << sg.fbits);
     for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = count[gb0 + i];
     __syncthreads();
@@ -630,6 +677,7 @@ __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict_
     uint32_t* gb = smem_u32 + nf;           // [nf] global position of the chunk's run of each bucket
     uint32_t* stage = smem_u32 + 2 * nf;    // [BIG_CHUNK]
     uint32_t* spos = stage + BIG_CHUNK;     // [BIG_CHUNK]
+    uint32_t* bnd = spos + BIG_CHUNK;       // [S + 1] sub-bin boundaries of the chunk's parent span (S > 1)
     __shared__ uint32_t wsum[BIGS_BLOCK / 64];
     const uint32_t total = cpre[sg.nbins], t = threadIdx.x;
     // XCD-aware order: workgroups go to the 8 XCDs round-robin, and the chunks of one span write 16-byte runs into the same ~1 MB of
@@ -641,9 +689,11 @@ __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict_
         const uint32_t it = x * per + q;
         if (it >= total) break;   // (uniform over the workgroup)
         const uint2 d = desc[it];
-        const uint32_t cn = min(binstart[d.x + 1], d.y + BIG_CHUNK) - d.y;
+        const uint32_t cn = min(binstart[(d.x + 1) * sg.S], d.y + BIG_CHUNK) - d.y;
         const uint32_t gb0 = (d.x / sg.cb) * half + ((d.x % sg.cb) << sg.fbits);
         for (uint32_t i = t; i < nf; i += BIGS_BLOCK) th[i] = 0;
+        if (sg.S > 1)
+            for (uint32_t i = t; i <= sg.S; i += BIGS_BLOCK) bnd[i] = binstart[d.x * sg.S + i];
         __syncthreads();
         E e[BIGS_ITEMS];
         uint32_t rank[BIGS_ITEMS];
@@ -669,7 +719,7 @@ __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict_
             const uint32_t s = k * BIGS_BLOCK + t;
             if (s < cn) {
                 const uint32_t f = entry_fine(e[k], sg.idxbits), slot = th[f] + rank[k];
-                stage[slot] = entry_sorted(e[k], sg.idxbits);
+                stage[slot] = entry_sorted(e[k], sg.idxbits) + (sg.S > 1 ? slice_of_position(bnd, sg.S, d.y + s) << sg.idxbits : 0u);
                 spos[slot] = gb[f] + rank[k];
             }
         }

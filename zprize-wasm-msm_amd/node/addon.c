@@ -47,6 +47,10 @@ static int (*p_conv[6])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
 static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
+static int (*p_prepare_bases)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint32_t, msm_amd_bases **);
+static int (*p_release_bases)(msm_amd_ctx *, msm_amd_bases *);
+static int (*p_bases_info)(const msm_amd_bases *, uint32_t *, uint64_t *);
+static int (*p_multiexp_prepared)(msm_amd_ctx *, msm_amd_bases *, uint32_t, const void *, uint32_t, uint32_t, uint8_t *);
 static int (*p_dist_id)(uint8_t *);
 static int (*p_dist_init)(msm_amd_ctx *, int, int, const uint8_t *);
 static int (*p_dist_destroy)(msm_amd_ctx *);
@@ -101,6 +105,10 @@ static const char *load_engine(void) {
     SYM(p_glv_dec, "msm_amd_glv_decompose_scalar")
     SYM(p_glv_endo, "msm_amd_glv_endomorphism")
     SYM(p_glv_pre, "msm_amd_glv_preprocess")
+    SYM(p_prepare_bases, "msm_amd_prepare_bases")
+    SYM(p_release_bases, "msm_amd_release_bases")
+    SYM(p_bases_info, "msm_amd_bases_info")
+    SYM(p_multiexp_prepared, "msm_amd_multiexp_prepared")
     SYM(p_dist_id, "msm_amd_dist_unique_id")
     SYM(p_dist_init, "msm_amd_dist_init")
     SYM(p_dist_destroy, "msm_amd_dist_destroy")
@@ -563,6 +571,171 @@ static napi_value js_multiexp_resident(napi_env env, napi_callback_info info) {
     return make_result(env, &c);
 }
 
+/* ---- prepared bases (msm_amd_prepare_bases): prepareBases(ctx, curve, group, flags, bases: Uint8Array, n, scalarBits) -> handle ;
+ *      multiexpPrepared(ctx, handle, scalars, scalarSize, n) -> Uint8Array ; multiexpPreparedAsync(...) -> Promise ; basesInfo(handle).
+ *      The window table of a prover's fixed points is built on the GPU once; every call then sorts all windows into one bucket set. */
+typedef struct {
+    msm_amd_ctx *ctx;
+    msm_amd_bases *h;
+    int curve, group;
+    uint32_t n;
+} prepared_t;
+static void prepared_finalize(napi_env env, void *data, void *hint) {
+    (void)env;
+    (void)hint;
+    prepared_t *b = (prepared_t *)data;
+    if (b) {
+        if (b->h && p_release_bases) p_release_bases(b->ctx, b->h);
+        free(b);
+    }
+}
+static napi_value js_prepare_bases(napi_env env, napi_callback_info info) {
+    size_t argc = 7;
+    napi_value argv[7];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    int curve, group;
+    uint32_t flags, n, bits = 0;
+    const uint8_t *p;
+    size_t lp;
+    if (argc < 6 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || get_i32(env, argv[1], &curve) || get_i32(env, argv[2], &group) ||
+        get_u32(env, argv[3], &flags) || get_bytes(env, argv[4], &p, &lp) || get_u32(env, argv[5], &n) || (argc >= 7 && get_u32(env, argv[6], &bits)) ||
+        (curve != 0 && curve != 1) || (group != 1 && group != 2)) {
+        napi_throw_type_error(env, NULL, "prepareBases(ctx, curve, group, flags, bases: Uint8Array, n[, scalarBits])");
+        return NULL;
+    }
+    flags &= MSM_AMD_BASES_JACOBIAN;
+    if (lp < (size_t)n * ((flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * n8_of(curve) * group) {
+        napi_throw_range_error(env, NULL, "bases buffer shorter than n points");
+        return NULL;
+    }
+    prepared_t *b = (prepared_t *)calloc(1, sizeof *b);
+    if (!b) return NULL;
+    b->ctx = (msm_amd_ctx *)ctx;
+    b->curve = curve;
+    b->group = group;
+    b->n = n;
+    if (p_prepare_bases(b->ctx, curve, group, flags, p, n, bits, &b->h)) {
+        napi_throw_error(env, "MSM_AMD_ERROR", p_last_error(b->ctx));
+        free(b);
+        return NULL;
+    }
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, b, prepared_finalize, NULL, &ext));
+    return ext;
+}
+static napi_value js_bases_info(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1], obj, v;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *hb;
+    if (argc < 1 || napi_get_value_external(env, argv[0], &hb) != napi_ok) {
+        napi_throw_type_error(env, NULL, "basesInfo(handle)");
+        return NULL;
+    }
+    uint32_t v6[6];
+    uint64_t tb = 0;
+    p_bases_info(((prepared_t *)hb)->h, v6, &tb);
+    static const char *names[6] = {"n", "scalarBits", "c", "windows", "signedWindows", "buckets"};
+    NAPI_OK(napi_create_object(env, &obj));
+    for (int i = 0; i < 6; ++i) {
+        NAPI_OK(napi_create_uint32(env, v6[i], &v));
+        NAPI_OK(napi_set_named_property(env, obj, names[i], v));
+    }
+    NAPI_OK(napi_create_double(env, (double)tb, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "tableBytes", v));
+    return obj;
+}
+typedef struct {
+    prepared_t *b;
+    uint32_t scalar_size, n;
+    const uint8_t *scalars;
+    uint8_t out[288];
+    int rc;
+    char err[256];
+    napi_async_work work;
+    napi_deferred deferred;
+    napi_ref ref_scalars, ref_handle;
+} pcall_t;
+static int parse_pcall(napi_env env, napi_callback_info info, pcall_t *c, napi_value *argv_out) {
+    size_t argc = 5;
+    napi_value argv[5];
+    if (napi_get_cb_info(env, info, &argc, argv, NULL, NULL) != napi_ok) return -1;
+    void *ctx, *hb;
+    size_t ls;
+    if (argc < 5 || napi_get_value_external(env, argv[0], &ctx) != napi_ok || napi_get_value_external(env, argv[1], &hb) != napi_ok ||
+        get_bytes(env, argv[2], &c->scalars, &ls) || get_u32(env, argv[3], &c->scalar_size) || get_u32(env, argv[4], &c->n)) {
+        napi_throw_type_error(env, NULL, "multiexpPrepared(ctx, basesHandle, scalars: Uint8Array, scalarSize, n)");
+        return -1;
+    }
+    c->b = (prepared_t *)hb;
+    if (c->b->ctx != (msm_amd_ctx *)ctx || ls < (size_t)c->n * c->scalar_size) {
+        napi_throw_range_error(env, NULL, "handle of another context, or scalars shorter than n elements");
+        return -1;
+    }
+    if (argv_out) {
+        argv_out[0] = argv[1];
+        argv_out[1] = argv[2];
+    }
+    return 0;
+}
+static napi_value presult(napi_env env, const pcall_t *c) {
+    size_t jsz = (size_t)3 * n8_of(c->b->curve) * c->b->group;
+    napi_value ab, arr;
+    void *data;
+    if (napi_create_arraybuffer(env, jsz, &data, &ab) != napi_ok) return NULL;
+    memcpy(data, c->out, jsz);
+    if (napi_create_typedarray(env, napi_uint8_array, jsz, ab, 0, &arr) != napi_ok) return NULL;
+    return arr;
+}
+static napi_value js_multiexp_prepared(napi_env env, napi_callback_info info) {
+    pcall_t c;
+    memset(&c, 0, sizeof c);
+    if (parse_pcall(env, info, &c, NULL)) return NULL;
+    if (p_multiexp_prepared(c.b->ctx, c.b->h, 0, c.scalars, c.scalar_size, c.n, c.out)) {
+        napi_throw_error(env, "MSM_AMD_ERROR", p_last_error(c.b->ctx));
+        return NULL;
+    }
+    return presult(env, &c);
+}
+static void pcall_exec(napi_env env, void *data) {
+    (void)env;
+    pcall_t *c = (pcall_t *)data;
+    c->rc = p_multiexp_prepared(c->b->ctx, c->b->h, 0, c->scalars, c->scalar_size, c->n, c->out);
+    if (c->rc) snprintf(c->err, sizeof c->err, "libmsm_amd error %d: %s", c->rc, p_last_error(c->b->ctx));
+}
+static void pcall_done(napi_env env, napi_status status, void *data) {
+    pcall_t *c = (pcall_t *)data;
+    if (status != napi_ok || c->rc) {
+        napi_value msg, err;
+        napi_create_string_utf8(env, c->rc ? c->err : "async work cancelled", NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, NULL, msg, &err);
+        napi_reject_deferred(env, c->deferred, err);
+    } else {
+        napi_resolve_deferred(env, c->deferred, presult(env, c));
+    }
+    napi_delete_reference(env, c->ref_scalars);
+    napi_delete_reference(env, c->ref_handle);   /* (the handle cannot be finalised, and its table freed, while a call uses it) */
+    napi_delete_async_work(env, c->work);
+    free(c);
+}
+static napi_value js_multiexp_prepared_async(napi_env env, napi_callback_info info) {
+    pcall_t *c = (pcall_t *)calloc(1, sizeof *c);
+    if (!c) return NULL;
+    napi_value keep[2], promise, name;
+    if (parse_pcall(env, info, c, keep)) {
+        free(c);
+        return NULL;
+    }
+    napi_create_reference(env, keep[0], 1, &c->ref_handle);
+    napi_create_reference(env, keep[1], 1, &c->ref_scalars);
+    napi_create_promise(env, &c->deferred, &promise);
+    napi_create_string_utf8(env, "msm_amd_multiexp_prepared", NAPI_AUTO_LENGTH, &name);
+    napi_create_async_work(env, NULL, name, pcall_exec, pcall_done, c, &c->work);
+    napi_queue_async_work(env, c->work);
+    return promise;
+}
+
 /* ---- batch conversions: batchConvert(ctx, which, curve, group, bytes) -> bytes
  *      which: 0 batchToAffine, 1 batchToJacobian, 2 batchLEMtoU, 3 batchUtoLEM ---------------------------- */
 static napi_value js_batch_convert(napi_env env, napi_callback_info info) {
@@ -794,6 +967,10 @@ static napi_value init(napi_env env, napi_value exports) {
         {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
         {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"prepareBases", NULL, js_prepare_bases, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"basesInfo", NULL, js_bases_info, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpPrepared", NULL, js_multiexp_prepared, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"multiexpPreparedAsync", NULL, js_multiexp_prepared_async, NULL, NULL, NULL, napi_enumerable, NULL},
         {"uploadBases", NULL, js_upload_bases, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpResident", NULL, js_multiexp_resident, NULL, NULL, NULL, napi_enumerable, NULL},
         {"batchConvert", NULL, js_batch_convert, NULL, NULL, NULL, napi_enumerable, NULL},

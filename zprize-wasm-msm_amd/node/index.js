@@ -176,6 +176,19 @@ function curve(curveName, opts) {
                 const scalarSize = Math.floor(buffScalars.byteLength / bases.n);
                 return native.multiexpResident(ctx, C.id, g, 0, bases.handle, buffScalars, scalarSize, bases.n);
             },
+            // the same SRS PREPARED (msm_amd_prepare_bases): its window table is built on the GPU once, every multiExp on it sorts all
+            // windows into one bucket set -- 13 instead of 16 bucket additions per pair at n = 2^20, a quarter less time at 2^16..2^18.
+            // scalarBits: the table serves scalars below 2^scalarBits (default: the curve order's bit length; a wider scalar rejects)
+            prepareBases: (buffBases, opts2) => {
+                const jac = !!(opts2 && opts2.jacobian);
+                const n = Math.floor(buffBases.byteLength / ((jac ? 3 : 2) * fsz));
+                const handle = native.prepareBases(ctx, C.id, g, jac ? FLAG_JACOBIAN : 0, buffBases, n, (opts2 && opts2.scalarBits) || 0);
+                return { handle, n, info: () => native.basesInfo(handle) };
+            },
+            multiExpPrepared: (prepared, buffScalars) => {
+                const scalarSize = Math.floor(buffScalars.byteLength / prepared.n);
+                return native.multiexpPreparedAsync(ctx, prepared.handle, buffScalars, scalarSize, prepared.n);
+            },
             multiExp: run(FLAG_JACOBIAN, 3 * fsz),
             multiExpAffine: run(0, 2 * fsz),
             // buffer-in / buffer-out forms of the batch conversions (ffjavascript exposes them under these names)

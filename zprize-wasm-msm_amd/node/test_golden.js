@@ -86,6 +86,13 @@ async function main() {
                     const outR = await Gx.multiExpResident(h, scalars);
                     if (Buffer.from(outR).toString("hex") !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: resident-bases result differs`);
                 }
+                // prepared bases: the window table built once (for the record's scalar width), every window into one bucket set
+                if (rec.n > 0 && rec.scalar_size * rec.n === scalars.length && rec.scalar_size <= 64) {
+                    const pb = Gx.prepareBases(bases, { jacobian: !affine, scalarBits: 8 * rec.scalar_size });
+                    if (pb.info().n !== rec.n) throw new Error("prepared bases: wrong point count");
+                    const outP = await Gx.multiExpPrepared(pb, scalars);
+                    if (Buffer.from(outP).toString("hex") !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: prepared-bases result differs`);
+                }
                 // surface 2: async, buffers in / Uint8Array out
                 if (rec.n > 0 && rec.scalar_size * rec.n === scalars.length) {
                     const out = await (affine ? Gx.multiExpAffine(bases, scalars) : Gx.multiExp(bases, scalars));
