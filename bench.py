@@ -281,19 +281,27 @@ def main():
     # calls in flight: 2 hide the latency-bound bucket reduction behind the next accumulation on one GPU; when the
     # windows are sharded 8 ways the accumulation per rank shrinks but the reduction latency does not, so more are needed
     # (tools/bench_shard.py on one GPU: 2 in flight is best up to 4 ranks, 4 at 8 ranks)
-    # How many: one probe call tells what a call of this rank consists of (profiles/r03_shard_per_rank_table.txt, both depths
-    # measured for every share): four in flight pay when the share is one of several window groups AND small (fewer than ~4 M
-    # (pair, window) entries: its accumulation then runs on its slot's own stream beside the others'); two otherwise.
+    # How many: one probe call tells what a call (of this rank) consists of -- profiles/r03_shard_per_rank_table.txt measured every
+    # share with two and with four in flight.  Four pay when the call is small -- fewer than 327 680 buckets (its accumulation then
+    # runs on its slot's own stream beside the others') and fewer than ~3.5 M (pair, window) entries -- and is not in the 8-bit-window
+    # regime (whose 64-lane slices fill the chip already): n = 2^16 / 2^17 on one GPU, the window groups of a sharded n <= 2^20.
     depth = 1
     if pipelined:
         depth = args.depth or 2
-        if sharded and not args.depth and plan["gw"] > 1:
-            C.multiexp_shard(g, pts, d_scalars, 32, count, rank % plan["gw"], plan["gw"])
+        if not args.depth and not args.host_buffers:
+            if prep is not None:
+                prep.multiexp(d_scalars)
+            elif sharded:
+                C.multiexp_shard(g, pts, d_scalars, 32, count, rank % plan["gw"], plan["gw"])
+            else:
+                C._multiexp(g, 0, pts, d_scalars, 32, n)
             gm = eng.geometry()
-            small = gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["windows_owned"] * count < (1 << 22)
-            flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=xdev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank keeps the same number of calls in flight
-            depth = 4 if int(flag.item()) == 1 else 2
+            small = (gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["entries"] < 3500000 and gm["buckets_per_window"] >= 4096)
+            if sharded:
+                flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=xdev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank keeps the same number of calls in flight
+                small = int(flag.item()) == 1
+            depth = 4 if small else 2
     eng.set_option("slots", max(depth, 1))
 
     xch = mdist.PartialExchange(args.curve, g, device=xdev) if sharded else None

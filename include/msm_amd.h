@@ -56,7 +56,7 @@ enum {
                                    SRS of a prover); the scalars are a host buffer copied over PCIe by every call    */
     MSM_AMD_BASES_IN_SUBGROUP = 16 /* the caller vouches that every base lies in the order-r subgroup (what
                                    msm_amd_batch_in_group_affine checks; true of any SRS).  Allows the engine's GLV schedule
-                                   (BLS12-381 G1, 98304 <= n <= 2^18), which reduces scalars mod r and uses the endomorphism: correct in
+                                   (BLS12-381 G1, 180000 <= n <= 2^18), which reduces scalars mod r and uses the endomorphism: correct in
                                    the subgroup only.  Without the flag the result is the reference's for ANY points of the curve. */
 };
 
@@ -85,7 +85,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * "split2" (0 = one lane per bucket always; default 1: G1 launches with few buckets cut their buckets into slices, one lane each), "splitk" (lanes per
  * bucket of such a launch: 0 = chosen per launch, 1..64 forced), "splitk_lanes" (the lane count that choice
  * brings a launch with few buckets to, default 327680), "reduce_pair" (1 = the G1 reduction with every point on a lane pair; measured
- * no faster, off by default); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
+ * no faster, off by default), "even_windows" (default 1: when the window size does not divide the scalar width the windows are
+ * c and c - 1 bits wide and tile it exactly -- no partly used top window; 0 = windows of c bits only, the round-2 layout),
+ * "dist_gw" (window groups of a call of a multi-GPU group: 0 = planned per call, else a divisor of the world size); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
  * interleaved multiply-add chains, 2 one chain) and "acc_stream" (0 by launch size, 1 the slot's own stream, 2 the context's stream A). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 /* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
@@ -299,7 +301,7 @@ int msm_amd_glv_preprocess(msm_amd_ctx *ctx, uint32_t flags, const void *points,
 /* The split the engine itself applies inside BLS12-381 G1 MSMs (not a reference export; exposed so that it can be
  * checked without a GPU): k == s * (k1 + k2*lambda) (mod r), |k1|, k2 < 2^127.  out32 = |k1| (16 bytes LE) || k2 (16 bytes);
  * *sign bit 0 = the P term is negative, bit 1 = the phi(P) term is negative.  Host only.  Option "glv"
- * (msm_amd_set_option): 0 = never split, 1 = where it pays (default: 98304 <= n <= 2^18), 2 = whenever it applies (n >= 1024; forces 16-bit windows).      */
+ * (msm_amd_set_option): 0 = never split, 1 = where it pays (default: 180000 <= n <= 2^18), 2 = whenever it applies (n >= 1024; forces 16-bit windows).      */
 int msm_amd_glv_split(const uint8_t *scalar32, uint8_t *out32, uint32_t *sign);
 
 /* ---- device memory + measurement utilities (bench / tests) ------------------------------------- */

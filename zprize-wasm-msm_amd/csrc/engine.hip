@@ -136,20 +136,20 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
 // tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
 // Other curves and groups scale the table; the choice of a split only needs its shape.
 static const float kShareMs[14][4] = {
-    {0.406f, 0.420f, 0.360f, 0.400f},       // 2^13
-    {0.467f, 0.422f, 0.357f, 0.400f},       // 2^14
-    {0.576f, 0.433f, 0.357f, 0.398f},       // 2^15
-    {0.800f, 0.487f, 0.383f, 0.398f},       // 2^16
-    {1.092f, 0.581f, 0.428f, 0.450f},       // 2^17
-    {1.260f, 0.741f, 0.541f, 0.503f},       // 2^18
-    {1.626f, 1.044f, 0.736f, 0.600f},       // 2^19
-    {2.581f, 1.556f, 0.947f, 0.720f},       // 2^20
-    {5.211f, 3.024f, 1.620f, 1.170f},       // 2^21
-    {10.946f, 6.049f, 3.144f, 1.913f},      // 2^22
-    {21.365f, 11.124f, 6.387f, 3.500f},     // 2^23
-    {37.102f, 21.665f, 11.681f, 6.415f},    // 2^24
-    {70.500f, 39.511f, 22.895f, 12.300f},   // 2^25
-    {137.072f, 77.712f, 45.111f, 23.623f},  // 2^26
+    {0.410f, 0.420f, 0.360f, 0.400f},       // 2^13
+    {0.468f, 0.423f, 0.359f, 0.400f},       // 2^14
+    {0.579f, 0.436f, 0.359f, 0.400f},       // 2^15
+    {0.580f, 0.494f, 0.385f, 0.421f},       // 2^16
+    {0.751f, 0.580f, 0.434f, 0.460f},       // 2^17
+    {1.258f, 0.734f, 0.540f, 0.501f},       // 2^18
+    {1.631f, 1.042f, 0.742f, 0.600f},       // 2^19
+    {2.610f, 1.534f, 0.948f, 0.719f},       // 2^20
+    {5.251f, 3.016f, 1.622f, 1.160f},       // 2^21
+    {10.937f, 6.044f, 3.146f, 1.867f},      // 2^22
+    {19.653f, 10.377f, 6.360f, 3.450f},     // 2^23
+    {36.763f, 19.482f, 11.603f, 6.370f},    // 2^24
+    {69.938f, 38.220f, 23.040f, 12.200f},   // 2^25
+    {136.283f, 75.330f, 45.272f, 23.237f},  // 2^26
 };
 static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
     if (n_slice == 0) return 0.0;
@@ -565,7 +565,13 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
         const uint32_t tile = wide ? 4096u : 1024u;
         const uint32_t ntile = (nv + tile - 1) / tile;
-        const size_t max_chunks = ((size_t)g.Wl * nve) / BIG_CHUNK + sg.nbins + 1;   // chunks of the spans that are cut up (k_big_*)
+        // chunks of the spans that are cut up (k_big_*): 8192 entries for 1024-lane workgroups on an idle chip, 4096 for 256-lane ones
+        // while other calls are in flight (sort_kernels.hpp)
+        // (measured, ms per MSM with two calls in flight, small | large chunks: n = 2^22 10.74 | 10.89, prepared 9.14 | 9.26, 2^23 19.32 | 19.36,
+        // 2^24 36.9 | 36.5, profiles/r03_chunk_mode.txt)
+        const bool small_chunks = ctx->chunk_mode ? ctx->chunk_mode == 1 : (others_pending && a.n < (1u << 24));
+        const uint32_t chunk = small_chunks ? (uint32_t)BIG_CHUNK_SMALL : (uint32_t)BIG_CHUNK;
+        const size_t max_chunks = ((size_t)g.Wl * nve) / chunk + sg.nbins + 1;
         if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * 4)) return rc;
         // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
         // well, ZeroMark in engine_ctx.hpp)
@@ -646,7 +652,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
 #undef MSM_TILE_SCATTER
         const uint32_t nf = 1u << sg.fbits;
         const size_t bnd_lds = sg.S > 1 ? ((size_t)sg.S + 1) * 4 : 0;   // sub-bin boundaries of one span
-        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * BIG_CHUNK) * 4 + bnd_lds;
+        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * chunk) * 4 + bnd_lds;
         // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
         // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
         // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
@@ -662,18 +668,25 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
             k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
         } else {
             if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 1024, BIG_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
             }
             const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
             HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
-            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, cpre);
-            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, desc);
+            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, chunk, cpre);
+            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, chunk, desc);
             k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-            k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, count);
+            k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, chunk, count);
             k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
             // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
             const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
-            k_big_scatter<uint32_t><<<bigs_grid, BIGS_BLOCK, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            if (small_chunks) {
+                // (256-lane workgroups: several per CU, so the grid is the number of chunks, not one resident wave per CU)
+                const uint32_t grid_s = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 2048);
+                k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL><<<grid_s, 256, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            } else {
+                k_big_scatter<uint32_t, 1024, BIG_CHUNK><<<bigs_grid, 1024, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+            }
         }
         k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
         k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
@@ -1338,6 +1351,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
+    if (!strcmp(name, "chunk_mode")) { ctx->chunk_mode = value; return 0; }     // experiments: chunk-parallel fine sort, 1 = 4096-entry chunks / 256 lanes, 2 = 8192 / 1024, 0 = by what else is in flight
     if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size
     if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A
     if (!strcmp(name, "acc_variant")) { ctx->acc_variant = value; return 0; }   // experiments: 1 = two-chain build, 2 = chained build, 0 = by launch size

@@ -148,7 +148,7 @@ struct msm_amd_ctx {
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int no_split2 = 0;      // option "split2" = 0: one lane per bucket always (switches k_accumulate_slices off)
-    uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0;
+    uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0, chunk_mode = 0;
     uint32_t splitk = 0;    // option "splitk": lanes per bucket of the G1 accumulation, 0 = chosen per launch, 1..MAX_SLICES forced
     uint32_t splitk_lanes = 5u * 1024u * 64u;   // option "splitk_lanes": the lane count a launch with few buckets is brought to (five waves for each of 1024 SIMDs)
     uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")

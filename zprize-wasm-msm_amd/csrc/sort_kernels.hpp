@@ -583,8 +583,12 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
 //                  cursor and is stored by consecutive lanes
 constexpr int BIG_ITEMS = 32;
 constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries (16384 were tried: no faster at n = 2^26, and 164 KB of LDS at 12 fine bits)
+// The chunk size is a launch parameter (`chunk`): 8192 with 1024-lane workgroups on an idle chip; 4096 with 256-lane workgroups while
+// other calls are in flight -- a 1024-lane workgroup with 82 KB of LDS can only start on a CU that has drained of accumulation waves
+// (twelve of them hold 107 KB of LDS and every register), a 256-lane one with 41 KB fits beside them as soon as one wave per SIMD retires.
+constexpr int BIG_CHUNK_SMALL = 4096;
 
-__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t S, uint32_t* __restrict__ cpre) {
+__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t S, uint32_t chunk, uint32_t* __restrict__ cpre) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t t = threadIdx.x;
@@ -595,7 +599,7 @@ __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ 
         uint32_t v = 0;
         if (i < nbins) {
             const uint32_t span = binstart[(i + 1) * S] - binstart[i * S];
-            v = span > (uint32_t)FINE_CAP ? (span + BIG_CHUNK - 1) / BIG_CHUNK : 0u;
+            v = span > (uint32_t)FINE_CAP ? (span + chunk - 1) / chunk : 0u;
         }
         uint32_t incl = v;
 #pragma unroll
@@ -615,7 +619,7 @@ __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ 
     if (t == 0) cpre[nbins] = carry_s;
 }
 __global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre, uint32_t nbins, uint32_t S,
-                                                   uint2* __restrict__ desc) {
+                                                   uint32_t chunk, uint2* __restrict__ desc) {
     const uint32_t total = cpre[nbins];
     for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < total; it += gridDim.x * blockDim.x) {
         uint32_t lo = 0, hi = nbins;   // largest bin with cpre[bin] <= it (bins without chunks repeat the value: take the last)
@@ -624,18 +628,18 @@ __global__ void __launch_bounds__(256) k_big_desc(const uint32_t* __restrict__ b
             if (cpre[mid] <= it) lo = mid;
             else hi = mid;
         }
-        desc[it] = make_uint2(lo, binstart[lo * S] + (it - cpre[lo]) * BIG_CHUNK);
+        desc[it] = make_uint2(lo, binstart[lo * S] + (it - cpre[lo]) * chunk);
     }
 }
 template <class E>
 __global__ void __launch_bounds__(SORT_BLOCK) k_big_hist(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
-                                                          const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t* __restrict__ count) {
+                                                          const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t chunk, uint32_t* __restrict__ count) {
     extern __shared__ uint32_t smem_u32[];
     uint32_t* h = smem_u32;   // [nf]
     const uint32_t nf = 1u << sg.fbits, total = cpre[sg.nbins], t = threadIdx.x;
     for (uint32_t it = blockIdx.x; it < total; it += gridDim.x) {
         const uint2 d = desc[it];
-        const uint32_t end = min(binstart[(d.x + 1) * sg.S], d.y + BIG_CHUNK);
+        const uint32_t end = min(binstart[(d.x + 1) * sg.S], d.y + chunk);
         for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
         __syncthreads();
         for (uint32_t p = d.y + t; p < end; p += SORT_BLOCK) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
@@ -666,18 +670,19 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __re
 }
 // (1024 lanes x 8 entries per chunk: the 82 KB of staging allow one workgroup per CU, and four waves per CU left the kernel waiting
 // on its own loads: 11.2 ms for 7 + 3.5 GB at n = 2^26)
-constexpr int BIGS_BLOCK = 1024, BIGS_ITEMS = BIG_CHUNK / BIGS_BLOCK;
-template <class E>
+constexpr int BIGS_BLOCK = 1024;
+template <class E, int BIGS_BLOCK, int CHUNK>
 __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, const uint32_t* __restrict__ cpre,
                                                              const uint2* __restrict__ desc, SortGeom sg, uint32_t half, uint32_t* __restrict__ bcursor,
                                                              uint32_t* __restrict__ sorted) {
+    constexpr int BIGS_ITEMS = CHUNK / BIGS_BLOCK;
     extern __shared__ uint32_t smem_u32[];
     const uint32_t nf = 1u << sg.fbits;
     uint32_t* th = smem_u32;                // [nf] chunk: counts, then exclusive starts inside the staged chunk
     uint32_t* gb = smem_u32 + nf;           // [nf] global position of the chunk's run of each bucket
-    uint32_t* stage = smem_u32 + 2 * nf;    // [BIG_CHUNK]
-    uint32_t* spos = stage + BIG_CHUNK;     // [BIG_CHUNK]
-    uint32_t* bnd = spos + BIG_CHUNK;       // [S + 1] sub-bin boundaries of the chunk's parent span (S > 1)
+    uint32_t* stage = smem_u32 + 2 * nf;    // [CHUNK]
+    uint32_t* spos = stage + CHUNK;     // [CHUNK]
+    uint32_t* bnd = spos + CHUNK;       // [S + 1] sub-bin boundaries of the chunk's parent span (S > 1)
     __shared__ uint32_t wsum[BIGS_BLOCK / 64];
     const uint32_t total = cpre[sg.nbins], t = threadIdx.x;
     // XCD-aware order: workgroups go to the 8 XCDs round-robin, and the chunks of one span write 16-byte runs into the same ~1 MB of
@@ -689,7 +694,7 @@ __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict_
         const uint32_t it = x * per + q;
         if (it >= total) break;   // (uniform over the workgroup)
         const uint2 d = desc[it];
-        const uint32_t cn = min(binstart[(d.x + 1) * sg.S], d.y + BIG_CHUNK) - d.y;
+        const uint32_t cn = min(binstart[(d.x + 1) * sg.S], d.y + CHUNK) - d.y;
         const uint32_t gb0 = (d.x / sg.cb) * half + ((d.x % sg.cb) << sg.fbits);
         for (uint32_t i = t; i < nf; i += BIGS_BLOCK) th[i] = 0;
         if (sg.S > 1)
