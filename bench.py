@@ -23,6 +23,8 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "zprize-wasm-msm
         sys.path.insert(0, p)
 
 R_BLS = 52435875175126190479447740508185965837690552500527637822603658699938581184513
+R_BN = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+R_ORDER = {"bls12381": R_BLS, "bn128": R_BN}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TMADS = 36.3         # v_mad_u64_u32 per second, measured at 2.4 GHz (profiles/r01_valu_rates_microbench.txt)
 # v_mad_u64_u32 per XYZZ mixed addition in the bucket kernels (6 products + 2 squarings + one fused two-product reduction):
@@ -35,16 +37,16 @@ MADS_PER_ADD = {("bls12381", 1): 6 * 392 + 2 * 301 + 588, ("bn128", 1): 6 * 162 
 VALU_PEAK_IDEAL_TMADS = 39.3   # the same chip at an ideal 4.0 cycles per wave-instruction: 1024 SIMDs x 16 lanes x 2.4 GHz
 
 
-def uniform_scalars_mod_r(n, seed):
-    """n scalars uniform in [0, r), 32 bytes little-endian each (rejection sampling on 255 bits)."""
+def uniform_scalars_mod_r(n, seed, r=R_BLS):
+    """n scalars uniform in [0, r), 32 bytes little-endian each (rejection sampling on the bit length of r)."""
     import numpy as np
     rng = np.random.default_rng(seed)
     out = np.empty((n, 4), dtype=np.uint64)
-    r_limbs = [(R_BLS >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
+    r_limbs = [(r >> (64 * i)) & ((1 << 64) - 1) for i in range(4)]
     todo = np.arange(n)
     while todo.size:
         cand = rng.integers(0, 1 << 64, size=(todo.size, 4), dtype=np.uint64)
-        cand[:, 3] &= np.uint64((1 << 63) - 1)
+        cand[:, 3] &= np.uint64((1 << (r.bit_length() - 192)) - 1)
         # lexicographic compare cand < r from the top limb
         lt = np.zeros(todo.size, dtype=bool)
         eq = np.ones(todo.size, dtype=bool)
@@ -197,7 +199,7 @@ def main():
     plan = eng.dist_plan(args.curve, g, 32, n, world, rank) if sharded else {"gp": 1, "gw": 1, "first": 0, "count": n}
     first, count = plan["first"], plan["count"]
     pts = C.gen_points(g, 0xC0FFEE02, count, first)
-    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02)[first:first + count]
+    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02, R_ORDER[args.curve])[first:first + count]      # below the curve's own group order
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
@@ -282,9 +284,10 @@ def main():
     # windows are sharded 8 ways the accumulation per rank shrinks but the reduction latency does not, so more are needed
     # (tools/bench_shard.py on one GPU: 2 in flight is best up to 4 ranks, 4 at 8 ranks)
     # How many: one probe call tells what a call (of this rank) consists of -- profiles/r03_shard_per_rank_table.txt measured every
-    # share with two and with four in flight.  Four pay when the call is small -- fewer than 327 680 buckets (its accumulation then
-    # runs on its slot's own stream beside the others') and fewer than ~3.5 M (pair, window) entries -- and is not in the 8-bit-window
-    # regime (whose 64-lane slices fill the chip already): n = 2^16 / 2^17 on one GPU, the window groups of a sharded n <= 2^20.
+    # share with two, three and four in flight.  A call whose accumulation is small -- fewer than 327 680 buckets, so that it runs on
+    # its slot's own stream beside the others', and not in the 8-bit-window regime, whose 64-lane slices fill the chip already --
+    # is best served by four in flight below ~1 M (pair, window) entries and by three up to ~10 M: n = 2^15 ... 2^18 on one GPU (2^18 at
+    # 14-bit windows: 1.22 | 1.02 | 1.15 ms with 2 | 3 | 4 in flight), the window groups of a sharded n <= 2^20.  Everything else: two.
     depth = 1
     if pipelined:
         depth = args.depth or 2
@@ -296,12 +299,16 @@ def main():
             else:
                 C._multiexp(g, 0, pts, d_scalars, 32, n)
             gm = eng.geometry()
-            small = (gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["entries"] < 3500000 and gm["buckets_per_window"] >= 4096)
+            small_acc = gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["buckets_per_window"] >= 4096
+            if prep is not None:
+                want = 4 if (small_acc and gm["entries"] < 3500000) else 2
+            else:
+                want = (4 if gm["entries"] < 1000000 else (3 if gm["entries"] < 10000000 else 2)) if small_acc else 2
             if sharded:
-                flag = torch.tensor([1 if small else 0], dtype=torch.int32, device=xdev)
+                flag = torch.tensor([want], dtype=torch.int32, device=xdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank keeps the same number of calls in flight
-                small = int(flag.item()) == 1
-            depth = 4 if small else 2
+                want = int(flag.item())
+            depth = want
     eng.set_option("slots", max(depth, 1))
 
     xch = mdist.PartialExchange(args.curve, g, device=xdev) if sharded else None
@@ -403,11 +410,13 @@ def main():
         acc_iso = iso_src.get("accumulate", 0.0)
         sc_iso = iso_src.get("histogram", 0) + iso_src.get("scan_order", 0) + iso_src.get("scatter", 0)
         sc_bytes = n * 32 + geom["entries"] * 4
-        sc_traffic = None
+        sc_traffic = sc_per_kernel = None
         pmc_s = os.path.join(ROOT, "profiles", "pmc_scatter.json")
         if os.path.exists(pmc_s) and headline:
             try:
-                sc_traffic = json.load(open(pmc_s)).get("hbm_bytes_per_call")
+                doc = json.load(open(pmc_s))
+                sc_traffic = doc.get("hbm_bytes_per_call")
+                sc_per_kernel = doc.get("per_kernel")     # {kernel: {us, moved MB, GB/s on moved bytes}}: measured with rocprofv3, this workload only
             except Exception:
                 sc_traffic = None
         mads = MADS_PER_ADD.get((args.curve, g))
@@ -457,6 +466,7 @@ def main():
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,
                                  # what the hardware counters say these kernels move (profiles/pmc_scatter.json), this workload only
                                  "traffic": sc_traffic,
+                                 "per_kernel": sc_per_kernel,
                                  "avg_ms_one_call_at_a_time": sc_iso,
                                  "frac_one_call_at_a_time": (sc_bytes / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_iso > 0 else None,
                                  "traffic_frac_of_peak": (sc_traffic / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_iso > 0) else None},

@@ -90,15 +90,15 @@ def main():
                     continue
                 gp = world // gw
                 count = (n + gp - 1) // gp
-                # two and four calls in flight: what pays depends on the size of the share (bench.py keeps four in flight when the
+                # two, three and four calls in flight: what pays depends on the size of the share (bench.py keeps four in flight when the
                 # share's accumulation is small enough to run on the slots' own streams, two otherwise)
                 per_depth = {}
-                for depth in (2, 4):
+                for depth in (2, 3, 4):
                     ms0, c = share(count, 0, gw, depth)
                     ms1 = share(count, gw - 1, gw, depth)[0] if gw > 1 else ms0
                     per_depth[depth] = max(ms0, ms1)
                 depth = min(per_depth, key=per_depth.get)
-                rows.append({"gp": gp, "gw": gw, "points_per_rank": count, "c": c, "ms_depth2": per_depth[2], "ms_depth4": per_depth[4],
+                rows.append({"gp": gp, "gw": gw, "points_per_rank": count, "c": c, "ms_depth2": per_depth[2], "ms_depth3": per_depth[3], "ms_depth4": per_depth[4],
                              "calls_in_flight": depth, "ms_busiest": per_depth[depth]})
             best = min(rows, key=lambda r: r["ms_busiest"])
             chosen = next(r for r in rows if r["gw"] == plan["gw"])
@@ -115,15 +115,15 @@ def main():
             print(f"n=2^{logn} ranks={world}: {cells}   planned {plan['gp']}x{plan['gw']} = {chosen['ms_busiest']:.3f} ms ({sp} of one GPU)"
                   f"{'' if (best['gp'], best['gw']) == (plan['gp'], plan['gw']) else f'   BEST {best_str(best)}'}", flush=True)
     # the same measurements by (points per rank, window groups): what the split policy's cost table is made of
-    print("# per-share cost: log2(points per rank), window groups -> ms at 2 | 4 calls in flight (window group 0)")
+    print("# per-share cost: points per rank, window groups -> ms at 2 | 3 | 4 calls in flight (window group 0)")
     shares = {}
     for (count, w, gw, depth), (ms, c) in sorted(memo.items()):
         if w == 0:
             shares.setdefault((count, gw), {})[depth] = ms
     for (count, gw), d in sorted(shares.items()):
-        print(f"share n_slice={count} gw={gw}: " + " | ".join(f"{d.get(k, float('nan')):.3f}" for k in (2, 4)))
+        print(f"share n_slice={count} gw={gw}: " + " | ".join(f"{d.get(k, float('nan')):.3f}" for k in (2, 3, 4)))
     if out:
-        out.write(json.dumps({"shares": [{"points": c_, "gw": g_, "ms_depth2": d.get(2), "ms_depth4": d.get(4)} for (c_, g_), d in sorted(shares.items())]}) + "\n")
+        out.write(json.dumps({"shares": [{"points": c_, "gw": g_, "ms_depth2": d.get(2), "ms_depth3": d.get(3), "ms_depth4": d.get(4)} for (c_, g_), d in sorted(shares.items())]}) + "\n")
     pts.free()
     eng.close()
 

@@ -70,7 +70,9 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     ctx->err = msg;
 }
 
-static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below, bool even = true) {
+// mid_from / mid_below: the range of n that takes 14-bit windows of even width (0, 0 = none)
+static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below, bool even = true, uint32_t mid_from = 0,
+                                 uint32_t mid_below = 0) {
     uint32_t c;
     if (forced) {
         c = forced;
@@ -112,12 +114,15 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
         // G1, 65537 for G2.  Widths between 9 and 15 lose to both: 256 is not a multiple of them and the few dense buckets of their
         // narrow top window set the duration of the accumulation.
         // With windows of even width (submit_msm) the sizes in between are usable: 14 bits -- 19 windows of 14 / 13 bits over 2^13
-        // buckets each -- from n = 49152 up to 2^18 for G1 (profiles/r03_even_windows_and_slices.txt, ms per MSM at c = 8 | 12 | 14 | 16:
-        // n = 2^16 .790 | .740 | .736 | 1.036, 2^17 1.103 | .991 | .862 | 1.105, 2^18 1.820 | 1.585 | 1.264 | 1.288; below, 8 bits stay
-        // ahead: 2^14 .488 | .577 | .639 | .983).  G2 and sharded calls keep the round-2 rule.
+        // buckets each.  ms per MSM, calls in flight as bench.py keeps them, c = 8 | 12 | 14 | 16 (profiles/r03_even_windows_and_slices.txt,
+        // r03_even_windows_other_curves.txt): BLS12-381 G1 n = 2^15 .587 | .618 | .471 | -, 2^16 .790 | .740 | .599 | 1.036, 2^17 1.103 | .991 |
+        // .762 | 1.105, 2^18 1.820 | 1.585 | 1.041 | 1.251 (three in flight), 2^19 - | - | 2.043 | 1.685; below 2^15, 8 bits stay ahead (2^14
+        // .488 | .577 | .639 | .983).  BN254 G1 2^16 .521 | .494 | .468 | .600, 2^17 .672 | .577 | .585 | .645, 2^18 1.087 | .797 | .761 | .759.
+        // BLS12-381 G2 2^16 1.707 | 1.553 | 1.401 | 1.759, 2^17 2.718 | 2.474 | 1.795 | 2.118, 2^18 4.726 | 4.657 | 3.152 | 2.918.  BN254 G2 gains
+        // nothing (2^16 1.229 | - | .953 | .953, 2^18 3.223 | - | 2.056 | 1.358) and keeps the round-2 rule, as do sharded calls.
         const uint32_t wide_from = nshards == 1 ? narrow_below : 4096u;
         c = n >= wide_from ? 16 : 8;
-        if (even && nshards == 1 && narrow_below == 98304u && n >= 49152u && n < (1u << 18)) c = 14;
+        if (even && nshards == 1 && mid_from && n >= mid_from && n < mid_below) c = 14;
     }
     if (c > nbits) c = nbits;
     if (c < 1) c = 1;
@@ -132,24 +137,24 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
 // consists of.  The estimate below is the per-rank cost model fitted to the measurements of tools/bench_shard.py (one rank's share run
 // alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
 // kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
-// many points, run alone on one MI355X with two or four calls in flight, whichever is faster (BLS12-381 G1, 255-bit scalars;
+// many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
 // tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
 // Other curves and groups scale the table; the choice of a split only needs its shape.
 static const float kShareMs[14][4] = {
-    {0.410f, 0.420f, 0.360f, 0.400f},       // 2^13
-    {0.468f, 0.423f, 0.359f, 0.400f},       // 2^14
-    {0.579f, 0.436f, 0.359f, 0.400f},       // 2^15
-    {0.580f, 0.494f, 0.385f, 0.421f},       // 2^16
-    {0.751f, 0.580f, 0.434f, 0.460f},       // 2^17
-    {1.258f, 0.734f, 0.540f, 0.501f},       // 2^18
-    {1.631f, 1.042f, 0.742f, 0.600f},       // 2^19
-    {2.610f, 1.534f, 0.948f, 0.719f},       // 2^20
-    {5.251f, 3.016f, 1.622f, 1.160f},       // 2^21
-    {10.937f, 6.044f, 3.146f, 1.867f},      // 2^22
-    {19.653f, 10.377f, 6.360f, 3.450f},     // 2^23
-    {36.763f, 19.482f, 11.603f, 6.370f},    // 2^24
-    {69.938f, 38.220f, 23.040f, 12.200f},   // 2^25
-    {136.283f, 75.330f, 45.272f, 23.237f},  // 2^26
+    {0.409f, 0.420f, 0.360f, 0.400f},       // 2^13
+    {0.468f, 0.422f, 0.358f, 0.400f},       // 2^14
+    {0.456f, 0.436f, 0.358f, 0.400f},       // 2^15
+    {0.537f, 0.493f, 0.385f, 0.407f},       // 2^16
+    {0.667f, 0.564f, 0.431f, 0.450f},       // 2^17
+    {1.018f, 0.646f, 0.494f, 0.507f},       // 2^18
+    {1.638f, 0.849f, 0.618f, 0.600f},       // 2^19
+    {2.642f, 1.502f, 0.890f, 0.720f},       // 2^20
+    {5.359f, 3.032f, 1.615f, 1.160f},       // 2^21
+    {11.084f, 5.868f, 3.367f, 1.853f},      // 2^22
+    {20.108f, 10.494f, 6.534f, 3.470f},     // 2^23
+    {38.002f, 20.000f, 11.852f, 6.484f},    // 2^24
+    {71.697f, 39.131f, 23.514f, 12.460f},   // 2^25
+    {139.552f, 76.830f, 46.491f, 23.944f},  // 2^26
 };
 static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
     if (n_slice == 0) return 0.0;
@@ -362,7 +367,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // applies, and that schedule is built on 16-bit windows
     auto window_bits = [&]() -> uint32_t {
         if (a.prepared) return a.prepared->c;   // the table fixes the window layout
-        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (KernelField<F>::chained_variant ? 98304u : 65537u), ctx->even_windows != 0);
+        // 14-bit windows: G1 of both curves from n = 2^15 to 3 x 2^17, BLS12-381 G2 from 49152 to 2^18 (pick_window_bits)
+        constexpr bool g1 = KernelField<F>::chained_variant, bls_g2 = std::is_same<F, Fp2<Bls12381Fp>>::value;
+        uint32_t c = pick_window_bits(a.n, a.nbits, ctx->force_c, a.nshards, ctx->no_split2 ? 4096u : (g1 ? 98304u : 65537u), ctx->even_windows != 0,
+                                      g1 ? 32768u : (bls_g2 ? 49152u : 0u), g1 ? 393216u : (bls_g2 ? (1u << 18) : 0u));
         if constexpr (GlvField<F>::value) {
             if (!ctx->force_c && ctx->glv_mode == 2 && a.n >= 1024 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) c = 16;
             // bases vouched to lie in the subgroup: from n ~ 180 000 the GLV schedule (8 windows of 16 bits over 2n half scalars) is ahead
