@@ -8,8 +8,8 @@
 //                     (window, bin) -> bin populations;  k_bin_scan: their exclusive scan = bin starts and cursors
 //   k_tile_scatter    same tiles, same digits: a counting sort of the tile's entries of four windows at a time in LDS, every
 //                     (tile, window, bin) run reserves its place with one atomic on the bin's cursor and is stored by consecutive
-//                     lanes -> partition entries {fine key | sign | index}, 4 bytes while fine bits + 1 + index bits <= 32
-//                     (n <= 2^23 at c = 16), 8 bytes beyond
+//                     lanes -> partition entries {fine key | sign | index}, 4 bytes at every size: an index wider than its field
+//                     puts its high bits into the bin (index slices, SortGeom)
 //   k_fine_small      one workgroup per (window, coarse bin) whose span fits the registers of a workgroup (<= FINE_CAP entries:
 //                     every call up to n ~ 2^20): the span is read ONCE, bucket count/offset come from an LDS histogram, the
 //                     span is permuted in LDS and written back as one coalesced stream
@@ -22,6 +22,8 @@
 // Round 1 kept 16-bit digit codes in HBM (written once, read twice), 8-byte entries (written once, read twice) and a (tile x bin)
 // count matrix with its scan: 713 MB per call at n = 2^20 against 101 MB algorithmic.  Recomputing the digits and reading each
 // span once brings that to ~270 MB, and nothing is 16 bits wide any more: windows up to 21 bits (8 coarse + 12 fine bits).
+// Round 2 still switched to 8-byte entries beyond n = 2^23; round 3 keeps 4 bytes there too (the template parameter E survives
+// with its one instantiation, uint32_t).
 #pragma once
 #include "engine_common.hpp"
 #include "glv.hpp"
@@ -288,15 +290,9 @@ template <>
 MSM_D uint32_t make_entry<uint32_t>(uint32_t idx, bool neg, uint32_t fine, uint32_t idxbits) {
     return idx | ((neg ? 1u : 0u) << idxbits) | (fine << (idxbits + 1));
 }
-template <>
-MSM_D uint2 make_entry<uint2>(uint32_t idx, bool neg, uint32_t fine, uint32_t) {
-    return make_uint2(idx | (neg ? 0x80000000u : 0u), fine);
-}
 MSM_D uint32_t entry_fine(uint32_t e, uint32_t idxbits) { return e >> (idxbits + 1); }
-MSM_D uint32_t entry_fine(uint2 e, uint32_t) { return e.y; }
 // index with the sign in bit 31: what the accumulation kernels read
 MSM_D uint32_t entry_sorted(uint32_t e, uint32_t idxbits) { return (e & ((1u << idxbits) - 1u)) | (((e >> idxbits) & 1u) << 31); }
-MSM_D uint32_t entry_sorted(uint2 e, uint32_t) { return e.x; }
 
 // block-wide exclusive scan of nf counters in LDS, in place; returns their sum.  Lane t owns the consecutive counters
 // [t*per, (t+1)*per), per = ceil(nf / BLOCK).  wsum: BLOCK / 64 words of LDS.
