@@ -3,7 +3,7 @@
 gp point slices x gw window groups (gp * gw = ranks) is timed as the share of its busiest rank run alone -- slice 0 (the longest)
 with window group 0 and with window group gw - 1 (the one that owns the partly filled top window), `depth` calls in flight as
 bench.py keeps them -- together with the split msm_amd_dist_plan picks.  The 8-GPU scaling run is the driver's; this table is
-what one rank of it has to do, and what the split policy (msm_dist_split in csrc/engine.hip) is fitted to.
+what one rank of it has to do, and what the split policy (msm_dist_split in csrc/dist.hip) is fitted to.
 
   python tools/shard_table.py [--logn 16 18 20 22 24 26] [--worlds 1 2 4 8] [--out gpurun_out/r03_shard_per_rank_table.jsonl]
 """

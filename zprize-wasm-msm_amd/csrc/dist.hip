@@ -3,7 +3,7 @@
 // to workers, and the linearity of the MSM over slices of the points (what that caller does above 2^22 points; :251-371 is one slice).
 //
 // One process per GPU.  The `world` ranks form gp point slices x gw window groups (gp * gw = world, chosen per call by
-// msm_dist_split in engine.hip): rank r = p * gw + w computes the windows {k : k mod gw = w} of slice p of the points on its own
+// msm_dist_split below): rank r = p * gw + w computes the windows {k : k mod gw = w} of slice p of the points on its own
 // MI355X (msm_amd_multiexp_shard_async), which leaves ONE Jacobian partial, already weighted by 2^(c*k).  The partials -- 144 bytes
 // for BLS12-381 G1, at most 288 for G2, behind a 16-byte status header -- cross xGMI in ONE ncclAllGather (elliptic-curve addition is
 // not an RCCL reduction operator, hence gather + add), and every rank adds them on the host.  Latency-bound by construction.
@@ -63,6 +63,73 @@ int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
 }
 
 }  // namespace
+
+// How a call of a multi-GPU group is split: gp point slices x gw window groups, gp * gw = world.  Both seams are the reference's own
+// (per-window fnName_chunk, build_multiexp.js:96-104; the full call as a sum over point slices, :251-371, which is what its external
+// caller does above 2^22 points).  Cutting the points keeps every rank's bucket count and halves the bucket populations; cutting the
+// windows keeps the populations and divides the buckets -- and with them the latency-bound reduction, which is what a small call
+// consists of.  The estimate below is the per-rank cost model fitted to the measurements of tools/bench_shard.py (one rank's share run
+// alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
+// kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
+// many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
+// tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
+// Other curves and groups scale the table; the choice of a split only needs its shape.
+static const float kShareMs[14][4] = {
+    {0.409f, 0.420f, 0.360f, 0.400f},       // 2^13
+    {0.468f, 0.422f, 0.358f, 0.400f},       // 2^14
+    {0.456f, 0.436f, 0.358f, 0.400f},       // 2^15
+    {0.537f, 0.493f, 0.385f, 0.407f},       // 2^16
+    {0.667f, 0.564f, 0.431f, 0.450f},       // 2^17
+    {1.018f, 0.646f, 0.494f, 0.507f},       // 2^18
+    {1.638f, 0.849f, 0.618f, 0.600f},       // 2^19
+    {2.642f, 1.502f, 0.890f, 0.720f},       // 2^20
+    {5.359f, 3.032f, 1.615f, 1.160f},       // 2^21
+    {11.084f, 5.868f, 3.367f, 1.853f},      // 2^22
+    {20.108f, 10.494f, 6.534f, 3.470f},     // 2^23
+    {38.002f, 20.000f, 11.852f, 6.484f},    // 2^24
+    {71.697f, 39.131f, 23.514f, 12.460f},   // 2^25
+    {139.552f, 76.830f, 46.491f, 23.944f},  // 2^26
+};
+static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
+    if (n_slice == 0) return 0.0;
+    const double lx = std::log2((double)n_slice), x = std::min(std::max(lx - 13.0, 0.0), 13.0);
+    const double y = std::min(std::max(std::log2((double)gw), 0.0), 3.0);
+    const int x0 = std::min((int)x, 12), y0 = std::min((int)y, 2);
+    const double fx = x - x0, fy = y - y0;
+    auto at = [&](int i, int j) { return std::log((double)kShareMs[i][j]); };   // interpolated in log space
+    double t = std::exp((1 - fx) * ((1 - fy) * at(x0, y0) + fy * at(x0, y0 + 1)) + fx * ((1 - fy) * at(x0 + 1, y0) + fy * at(x0 + 1, y0 + 1)));
+    if (lx > 26.0) t *= (double)n_slice / 67108864.0;   // beyond the table: linear in the points
+    if (gw > 8) t *= 8.0 / gw;                          // (more window groups than measured: fewer windows each)
+    return t;
+}
+void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw) {
+    *gp = 1;
+    *gw = world ? world : 1;
+    if (world <= 1) return;
+    if (ctx->dist_gw && world % ctx->dist_gw == 0) {
+        *gw = ctx->dist_gw;
+        *gp = world / ctx->dist_gw;
+        return;
+    }
+    (void)curve;
+    (void)group;
+    (void)scalar_size;
+    // the split whose busiest rank -- slice 0, the longest -- is estimated fastest; near-ties (3 %) go to more point slices: the ranks
+    // then hold less of the inputs
+    double best = 1e300;
+    for (uint32_t p = world; p >= 1; --p) {
+        if (world % p) continue;
+        const uint32_t w = world / p;
+        const uint32_t n_slice = (uint32_t)(((uint64_t)n + p - 1) / p);
+        if (p > 1 && n_slice < 1024) continue;   // slices this small are all fixed cost
+        const double t = shard_cost_ms(n_slice, w);
+        if (t < best * 0.97) {
+            best = t;
+            *gw = w;
+            *gp = p;
+        }
+    }
+}
 
 extern "C" {
 

@@ -130,208 +130,6 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
     return c;
 }
 
-// How a call of a multi-GPU group is split: gp point slices x gw window groups, gp * gw = world.  Both seams are the reference's own
-// (per-window fnName_chunk, build_multiexp.js:96-104; the full call as a sum over point slices, :251-371, which is what its external
-// caller does above 2^22 points).  Cutting the points keeps every rank's bucket count and halves the bucket populations; cutting the
-// windows keeps the populations and divides the buckets -- and with them the latency-bound reduction, which is what a small call
-// consists of.  The estimate below is the per-rank cost model fitted to the measurements of tools/bench_shard.py (one rank's share run
-// alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
-// kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
-// many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
-// tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
-// Other curves and groups scale the table; the choice of a split only needs its shape.
-static const float kShareMs[14][4] = {
-    {0.409f, 0.420f, 0.360f, 0.400f},       // 2^13
-    {0.468f, 0.422f, 0.358f, 0.400f},       // 2^14
-    {0.456f, 0.436f, 0.358f, 0.400f},       // 2^15
-    {0.537f, 0.493f, 0.385f, 0.407f},       // 2^16
-    {0.667f, 0.564f, 0.431f, 0.450f},       // 2^17
-    {1.018f, 0.646f, 0.494f, 0.507f},       // 2^18
-    {1.638f, 0.849f, 0.618f, 0.600f},       // 2^19
-    {2.642f, 1.502f, 0.890f, 0.720f},       // 2^20
-    {5.359f, 3.032f, 1.615f, 1.160f},       // 2^21
-    {11.084f, 5.868f, 3.367f, 1.853f},      // 2^22
-    {20.108f, 10.494f, 6.534f, 3.470f},     // 2^23
-    {38.002f, 20.000f, 11.852f, 6.484f},    // 2^24
-    {71.697f, 39.131f, 23.514f, 12.460f},   // 2^25
-    {139.552f, 76.830f, 46.491f, 23.944f},  // 2^26
-};
-static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
-    if (n_slice == 0) return 0.0;
-    const double lx = std::log2((double)n_slice), x = std::min(std::max(lx - 13.0, 0.0), 13.0);
-    const double y = std::min(std::max(std::log2((double)gw), 0.0), 3.0);
-    const int x0 = std::min((int)x, 12), y0 = std::min((int)y, 2);
-    const double fx = x - x0, fy = y - y0;
-    auto at = [&](int i, int j) { return std::log((double)kShareMs[i][j]); };   // interpolated in log space
-    double t = std::exp((1 - fx) * ((1 - fy) * at(x0, y0) + fy * at(x0, y0 + 1)) + fx * ((1 - fy) * at(x0 + 1, y0) + fy * at(x0 + 1, y0 + 1)));
-    if (lx > 26.0) t *= (double)n_slice / 67108864.0;   // beyond the table: linear in the points
-    if (gw > 8) t *= 8.0 / gw;                          // (more window groups than measured: fewer windows each)
-    return t;
-}
-void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw) {
-    *gp = 1;
-    *gw = world ? world : 1;
-    if (world <= 1) return;
-    if (ctx->dist_gw && world % ctx->dist_gw == 0) {
-        *gw = ctx->dist_gw;
-        *gp = world / ctx->dist_gw;
-        return;
-    }
-    (void)curve;
-    (void)group;
-    (void)scalar_size;
-    // the split whose busiest rank -- slice 0, the longest -- is estimated fastest; near-ties (3 %) go to more point slices: the ranks
-    // then hold less of the inputs
-    double best = 1e300;
-    for (uint32_t p = world; p >= 1; --p) {
-        if (world % p) continue;
-        const uint32_t w = world / p;
-        const uint32_t n_slice = (uint32_t)(((uint64_t)n + p - 1) / p);
-        if (p > 1 && n_slice < 1024) continue;   // slices this small are all fixed cost
-        const double t = shard_cost_ms(n_slice, w);
-        if (t < best * 0.97) {
-            best = t;
-            *gw = w;
-            *gp = p;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Prepared bases: the window table of a fixed set of points (the SRS of a prover; reference caller shape
-// wasmcurves/benchmarks/multiexp.js:18-41: the same bases, call after call).
-// table[w][i] = 2^(start bit of window w) * P_i, affine.  With it the digit of EVERY window of scalar i selects a point that goes into
-// the SAME bucket set: the buckets, their reduction and the host's Horner loop shrink from W windows' worth to one, which in turn
-// lets the windows be wider -- n = 2^20: 13 windows of 20 / 19 bits over 2^19 buckets instead of 16 windows x 2^15 buckets:
-// 13 instead of 16 bucket additions per pair at the same number of buckets.
-// ------------------------------------------------------------------------------------------
-namespace msm {
-// next[i] = 2^ndbl * prev[i]: K points per lane, ndbl doublings each in extended Jacobian coordinates, back to affine with one shared
-// inversion per lane (Montgomery's trick, as k_jacobian_to_affine).  One-off work: loops are kept rolled.
-template <class F>
-__global__ void __launch_bounds__(256) k_table_next(const uint8_t* __restrict__ prev, uint32_t n, uint32_t ndbl, uint8_t* __restrict__ next) {
-    constexpr int K = 4;
-    const uint32_t first = (blockIdx.x * blockDim.x + threadIdx.x) * K;
-    if (first >= n) return;
-    XYZZ<F> p[K];
-    F pref[K];
-    F acc = F::one();
-#pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-        const uint32_t i = first + k;
-        XYZZ<F> q = XYZZ<F>::inf();
-        if (i < n) q = XYZZ<F>::from_affine(load16<Affine<F>>(prev + (size_t)i * sizeof(Affine<F>)));
-#pragma unroll 1
-        for (uint32_t d = 0; d < ndbl; ++d) q = XYZZ<F>::dbl(q);
-        p[k] = q;
-        pref[k] = acc;
-        if (!q.is_inf()) acc = F::mul(acc, F::mul(q.zz, q.zzz));
-    }
-    F inv = F::inv(acc);
-#pragma unroll 1
-    for (int k = K - 1; k >= 0; --k) {
-        const uint32_t i = first + k;
-        if (i >= n) continue;
-        Affine<F> a{F::zero(), F::zero()};
-        if (!p[k].is_inf()) {
-            const F t = F::mul(inv, pref[k]);          // 1 / (zz * zzz) of this point
-            inv = F::mul(inv, F::mul(p[k].zz, p[k].zzz));
-            a.x = F::mul(p[k].x, F::mul(t, p[k].zzz));   // x = X / ZZ
-            a.y = F::mul(p[k].y, F::mul(t, p[k].zz));    // y = Y / ZZZ
-        }
-        store16(next + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
-    }
-}
-}  // namespace msm
-
-// Window layout of a table for n points and scalars below 2^bits: `ns` signed windows of c bits followed by W - ns unsigned ones of
-// c - 1 bits (both kinds fill 2^(c-1) buckets evenly), the top one unsigned, W the fewest that cover `bits`, ns the fewest that do
-// it with W.  The window size, measured (profiles/r03_sweep_prepared_window_bits.txt, BLS12-381 G1, ms per MSM with two calls in
-// flight, c | ms: n = 2^16  14 .636, 15 .617, 16 .602, 17 .648;  2^18  16 1.167, 17 .983, 18 .981, 19 1.099;  2^20  18 3.05, 19 3.01,
-// 20 2.55, 21 3.32;  2^22  19 11.4, 20 9.8, 21 10.5;  2^24  20 36.1, 21 38.7): c = log2 n up to 2^18, 20 from 2^19 on.  What decides is
-// not only W x n bucket additions against 2^(c-1) buckets to reduce: 2^18 buckets are 4096 accumulation waves, 1.33 rounds of the
-// 3072 that fit the chip, and the last third of a round costs almost a whole one (c = 19 at n = 2^20: 28 % more time per addition
-// than c = 20, whose 8192 waves are 2.67 rounds -- the same as the 16 x 2^15 buckets of the general path); 2^20 buckets (c = 21) hold
-// 13 entries each and the per-bucket costs show.  Below 2^16 the plain count decides: W x n additions + ~12 additions' worth per bucket.
-static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t* c_out, uint32_t* W_out, uint32_t* ns_out) {
-    auto layout = [&](uint32_t c, uint32_t* W, uint32_t* ns) {
-        // W windows, ns of them signed (c bits), cover W (c - 1) + ns bits; ns <= W - 1 because the top window is unsigned
-        *W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
-        *ns = bits > *W * (c - 1) ? bits - *W * (c - 1) : 0u;
-        return (uint64_t)*W * (((uint64_t)n + 4095u) & ~4095ull) < (1ull << 31);   // (table rows are padded to 4096 points)
-    };
-    *c_out = *W_out = *ns_out = 0;
-    uint32_t want = forced_c;
-    if (!want && n >= (1u << 16)) {
-        uint32_t lg = 0;
-        while ((2ull << lg) <= n) ++lg;   // floor(log2 n)
-        want = n >= (1u << 19) ? 20u : lg;
-    }
-    if (want) {
-        // (a table too large for 31-bit entry indices at the wanted size takes the nearest wider window that fits)
-        for (uint32_t c = std::min<uint32_t>(want, MAX_WINDOW_BITS); c <= (uint32_t)MAX_WINDOW_BITS; ++c)
-            if (layout(c, W_out, ns_out)) {
-                *c_out = c;
-                return;
-            }
-        *W_out = *ns_out = 0;
-        return;
-    }
-    uint64_t best = ~0ull;
-    for (uint32_t c = 3; c <= 16u; ++c) {
-        uint32_t W, ns;
-        if (!layout(c, &W, &ns)) continue;
-        const uint64_t cost = (uint64_t)W * n + 12ull * (1ull << (c - 1));
-        if (cost < best) {
-            best = cost;
-            *c_out = c;
-            *W_out = W;
-            *ns_out = ns;
-        }
-    }
-}
-
-template <class F>
-static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, uint32_t flags) {
-    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
-    const uint32_t n = h->n;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    h->stride = (n + 4095u) & ~4095u;
-    const size_t row = (size_t)h->stride * ASZ;
-    h->table_bytes = (size_t)h->W * row;
-    HIPCHK(ctx, hipMalloc(&h->table, h->table_bytes));
-    hipStream_t st = ctx->stream_s;
-    uint8_t* t0 = (uint8_t*)h->table;
-    const bool dev = (flags & (MSM_AMD_DEVICE_PTRS | MSM_AMD_DEVICE_BASES)) != 0;
-    if (flags & MSM_AMD_BASES_JACOBIAN) {
-        void* dj = const_cast<void*>(bases);
-        if (!dev) {
-            HIPCHK(ctx, hipMalloc(&dj, (size_t)n * JSZ));
-            if (hipMemcpyAsync(dj, bases, (size_t)n * JSZ, hipMemcpyHostToDevice, st) != hipSuccess) {
-                (void)hipFree(dj);
-                msm_set_err(ctx, "prepare_bases: copy of the bases failed");
-                return MSM_AMD_EHIP;
-            }
-        }
-        k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)dj, n, t0);
-        hipError_t e = hipStreamSynchronize(st);
-        if (!dev) (void)hipFree(dj);
-        HIPCHK(ctx, e);
-    } else {
-        HIPCHK(ctx, hipMemcpyAsync(t0, bases, (size_t)n * ASZ, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    }
-    Geom g{};
-    g.c = h->c;
-    g.ns = h->ns;
-    for (uint32_t w = 1; w < h->W; ++w) {
-        const uint32_t ndbl = window_start_bit(g, w) - window_start_bit(g, w - 1);
-        k_table_next<F><<<((n + 3) / 4 + 255) / 256, 256, 0, st>>>(t0 + (size_t)(w - 1) * row, n, ndbl, t0 + (size_t)w * row);
-    }
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    HIPCHK(ctx, hipGetLastError());
-    return 0;
-}
-
 struct RunArgs {
     const void* bases;
     const void* scalars;
@@ -345,18 +143,52 @@ struct RunArgs {
 template <class F>
 static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out);
 
+// One submission of the engine, stage by stage.  The members are what the stages share: where the inputs live, the window geometry,
+// the slot's tables, the streams.  plan() decides everything (window layout, GLV schedule, limits) and brings the inputs to the GPU;
+// sort() queues stages 1-3 on the sort stream, accumulate() stage 4, reduce() stage 5 and the downloads of the partials.
 template <class F>
-static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
+struct MsmCall {
     using X = XYZZ<F>;
     using FK = typename KernelField<F>::type;
-    const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);   // packed images
-    const size_t BSZ = bucket_bytes<FK>();                                               // one bucket in HBM
+    static constexpr size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>), XSZ = sizeof(X);   // packed images
+    static constexpr int kNothingToQueue = 1;   // plan(): the result is infinity (n == 0, empty bit range, no owned window)
+    msm_amd_ctx* ctx;
+    Slot* sl;
+    const RunArgs& a;
+    const size_t BSZ = bucket_bytes<FK>();   // one bucket in HBM
+    bool others_pending = false, use_glv = false, split_mode = false;
+    hipStream_t st = nullptr;                // the stream the current stage queues on
+    const uint8_t *d_bases = nullptr, *d_scalars = nullptr, *d_xbeta = nullptr;
+    Geom g{};
+    uint32_t nv = 0, nve = 0, NB = 0, nblk = 0, oblk = 0, w_split = 0, split = 0;
+    uint32_t *count = nullptr, *offset = nullptr, *order = nullptr, *bins = nullptr, *sorted = nullptr;
+    uint8_t* buckets = nullptr;
+
+    MsmCall(msm_amd_ctx* c, Slot* s, const RunArgs& args) : ctx(c), sl(s), a(args) {}
+    int plan();
+    int sort();
+    int accumulate();
+    int reduce();
+};
+
+template <class F>
+static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
+    MsmCall<F> call(ctx, sl, a);
+    if (int rc = call.plan()) return rc == MsmCall<F>::kNothingToQueue ? 0 : rc;
+    if (int rc = call.sort()) return rc;
+    if (int rc = call.accumulate()) return rc;
+    return call.reduce();
+}
+
+// ---- the call's plan: inputs on the GPU, window layout, schedule, limits, the slot's tables
+template <class F>
+int MsmCall<F>::plan() {
     sl->trivial = false;
     sl->raw_out = a.raw_out;
     sl->finish = &finish_msm<F>;
     if (a.n == 0 || a.nbits == 0) {
         sl->trivial = true;
-        return 0;
+        return kNothingToQueue;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // everything up to the sorted index lists runs on stream S -- or S2 when the accumulation will be small: such calls run their
@@ -381,7 +213,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         }
         return c;
     };
-    bool others_pending = false;
+    others_pending = false;
     for (uint32_t k = 0; k < ctx->nslots; ++k) others_pending |= (&ctx->slots[k] != sl && ctx->slots[k].pending);
     bool small_est;
     {
@@ -393,15 +225,13 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         // with a full-size accumulation ~5 % (measured); of another priority because only such streams never share a queue with S/A/B
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_s2, hipStreamNonBlocking, 1));
     }
-    hipStream_t st = small_est ? ctx->stream_s2 : ctx->stream_s;
+    st = small_est ? ctx->stream_s2 : ctx->stream_s;
     const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
     const bool dev_bases = a.prepared || dev_scalars || (a.flags & MSM_AMD_DEVICE_BASES) != 0;
     const bool jac = !a.prepared && (a.flags & MSM_AMD_BASES_JACOBIAN) != 0;
     const size_t base_bytes = (size_t)a.n * (jac ? JSZ : ASZ);
     const size_t scalar_bytes = (size_t)a.n * a.scalar_size;
 
-    const uint8_t* d_bases;
-    const uint8_t* d_scalars;
     if (dev_bases) {
         if (((uintptr_t)a.bases & 15) != 0) {
             msm_set_err(ctx, "device bases pointer must be 16-byte aligned");
@@ -421,7 +251,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         d_scalars = (const uint8_t*)sl->d_scalars.p;
     }
 
-    Geom g;
+    g = Geom{};
     g.n = a.n;
     g.scalar_size = a.scalar_size;
     g.bit_lo = a.bit_lo;
@@ -460,11 +290,11 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     // the accumulation dominates and 8 x 2^15 buckets give only 4096 accumulation waves, which quantise badly over
     // 1024 SIMDs x 3 waves (measured 3-15 % slower), so larger calls keep the 16-window schedule unless option "glv" = 2
     // forces the path (tests, experiments).
-    bool use_glv = false;
+    use_glv = false;
     if constexpr (GlvField<F>::value)
         use_glv = !a.prepared && (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
                   (a.n <= (1u << 18) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
-    const uint32_t nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
+    nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
         g.n = nv;
         g.nbits = 128;
@@ -480,7 +310,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         msm_set_err(ctx, "windows x points of a prepared table must stay below 2^31");
         return MSM_AMD_EINVAL;
     }
-    const uint32_t nve = (uint32_t)nve64;
+    nve = (uint32_t)nve64;
     // (pair, window) positions -- Mscan, offset, delta, the indices into tmp/sorted -- are 32-bit: the entries of one pass must
     // number fewer than 2^32 (17 windows x 2^27 points fit; 33 windows of 64-byte scalars or a forced narrow window would wrap)
     if ((uint64_t)g.Wl * nve >= (1ull << 32)) {
@@ -495,9 +325,9 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     sl->g = g;
     if (g.Wl == 0) {
         sl->trivial = true;
-        return 0;
+        return kNothingToQueue;
     }
-    const uint32_t NB = g.Wl * g.half;
+    NB = g.Wl * g.half;
 
     HIPCHK(ctx, hipEventRecord(sl->ev[0], st));
     // ---- Jacobian bases -> affine
@@ -507,7 +337,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_affine.p);
         d_bases = (const uint8_t*)sl->d_affine.p;
     }
-    const uint8_t* d_xbeta = nullptr;
+    d_xbeta = nullptr;
     if constexpr (GlvField<F>::value) {
         if (use_glv) {
             if (int rc = ensure(ctx, sl->d_xbeta, (size_t)a.n * sizeof(F))) return rc;
@@ -524,182 +354,192 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (int rc = ensure(ctx, sl->d_sorted, (size_t)g.Wl * nve * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_flags, 16)) return rc;
     if (int rc = ensure(ctx, sl->d_buckets, (size_t)NB * BSZ)) return rc;
-    uint32_t* count = (uint32_t*)sl->d_count.p;
-    uint32_t* offset = (uint32_t*)sl->d_offset.p;
-    uint32_t* order = (uint32_t*)sl->d_order.p;
-    uint32_t* bins = (uint32_t*)sl->d_bins.p;
-    uint32_t* sorted = (uint32_t*)sl->d_sorted.p;
+    count = (uint32_t*)sl->d_count.p;
+    offset = (uint32_t*)sl->d_offset.p;
+    order = (uint32_t*)sl->d_order.p;
+    bins = (uint32_t*)sl->d_bins.p;
+    sorted = (uint32_t*)sl->d_sorted.p;
 
-    const uint32_t nblk = (a.n + 255) / 256;
-    const uint32_t oblk = std::max(1u, std::min(512u, NB / 2048u));
+    nblk = (a.n + 255) / 256;
+    oblk = std::max(1u, std::min(512u, NB / 2048u));
     // A lone call (nothing else in flight) is latency-bound at its end: the bucket reduction is ~40 dependent additions deep
     // on one wave per SIMD.  Optionally (option "split") its windows are handled as two groups, the reduction of the first
     // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
     // reduction waves leave room for only one accumulation wave per SIMD, and two launches have two tails.  Kept for
     // experiments, off by default; overlapping across calls (slots) is what pays.
-    const bool split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
-    const uint32_t w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
-    const uint32_t split = w_split * g.half;                                               // first bucket of the second group
-    {
-        // ---- 1. populations of the (owned window, coarse bin) pairs -- digits recomputed from the scalars, never stored
-        SortGeom sg;
-        // fine key: 8 bits up to c = 17 (at c = 16: 128 coarse bins, spans of n / 128 entries -- one workgroup reads a span once up
-        // to n = 2^20 -- and runs of tile / 128 entries in the partition), then 8 coarse bits and the rest fine
-        sg.fbits = g.c - 1 <= 16u ? std::min(g.c - 1, 8u) : g.c - 1 - 8u;
-        sg.cbits = g.c - 1 - sg.fbits;
-        sg.cb = 1u << sg.cbits;
-        sg.nbins = g.Wl * sg.cb;
-        // 4-byte partition entries {fine key | sign | index} at every size: the index field takes what the fine key and the sign leave
-        // of 32 bits; wider indices (n > 2^23 at c = 16, the W x n table indices of prepared bases) put their HIGH bits into the bin --
-        // S sub-bins per (window, coarse bin), see SortGeom
-        const uint64_t max_index = g.merged ? (uint64_t)g.W * g.stride : (uint64_t)nv;
-        sg.idxbits = 1;
-        while ((1ull << sg.idxbits) < max_index) ++sg.idxbits;
-        sg.idxbits = std::min(sg.idxbits, 31u - sg.fbits);
-        sg.S = (uint32_t)((max_index + (1ull << sg.idxbits) - 1) >> sg.idxbits);
-        if (sg.S == 0) sg.S = 1;
-        if (sg.S > 2048u) {
-            msm_set_err(ctx, "too many points for one pass of the sort (index slices > 2048): fewer points per call");
-            return MSM_AMD_EINVAL;
-        }
-        const size_t nsub = (size_t)sg.nbins * sg.S;   // bins the partition scatters into
-        // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
-        // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
-        // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
-        // 100 KB of LDS has to wait for a whole CU to drain of the long-running accumulation waves of the calls already in flight: with
-        // another call pending the small tiles give the better THROUGHPUT up to n = 2^22 (n = 2^20: 2.59-2.60 against 2.62-2.63 ms per
-        // MSM, 2^22: 10.80 against 10.95; equal from 2^24), and for the ranks of a many-way shard, which keep four calls in flight, at
-        // every size (8 ranks: n = 2^20 0.74 -> 0.70 ms per call, 2^22 2.19 -> 2.00, 2^26 24.7 -> 24.2; 2 % the other way at 4 ranks).
-        const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
-        const uint32_t tile = wide ? 4096u : 1024u;
-        const uint32_t ntile = (nv + tile - 1) / tile;
-        // chunks of the spans that are cut up (k_big_*): 8192 entries for 1024-lane workgroups on an idle chip, 4096 for 256-lane ones
-        // while other calls are in flight (sort_kernels.hpp)
-        // (measured, ms per MSM with two calls in flight, small | large chunks: n = 2^22 10.74 | 10.89, prepared 9.14 | 9.26, 2^23 19.32 | 19.36,
-        // 2^24 36.9 | 36.5, profiles/r03_chunk_mode.txt)
-        const bool small_chunks = ctx->chunk_mode ? ctx->chunk_mode == 1 : (others_pending && a.n < (1u << 24));
-        const uint32_t chunk = small_chunks ? (uint32_t)BIG_CHUNK_SMALL : (uint32_t)BIG_CHUNK;
-        const size_t max_chunks = ((size_t)g.Wl * nve) / chunk + sg.nbins + 1;
-        if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * 4)) return rc;
-        // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
-        // well, ZeroMark in engine_ctx.hpp)
-        if (int rc = ensure(ctx, sl->d_binhist, nsub * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_binstart, (nsub + 1) * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_bincur, nsub * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
-        if (int rc = ensure(ctx, sl->d_desc, max_chunks * 8)) return rc;
-        if (int rc = ensure(ctx, sl->d_bcursor, (size_t)NB * 4)) return rc;
-        uint32_t* binhist = (uint32_t*)sl->d_binhist.p;
-        uint32_t* binstart = (uint32_t*)sl->d_binstart.p;
-        uint32_t* bincur = (uint32_t*)sl->d_bincur.p;
-        uint32_t* cpre = (uint32_t*)sl->d_cpre.p;
-        uint2* desc = (uint2*)sl->d_desc.p;
-        uint32_t* bcursor = (uint32_t*)sl->d_bcursor.p;
-        // where the digits come from: 0 = any scalar size / bit range (bits read from memory per window), 8 = whole 32-byte scalars in
-        // registers, 4 = the 16-byte halves of the GLV schedule
-        const uint8_t* d_items = d_scalars;
-        int nw = 0;
-        if (use_glv) {
-            if (int rc = ensure(ctx, sl->d_halves, (size_t)nv * 16)) return rc;
-            k_glv_halves<<<nblk, 256, 0, st>>>(d_scalars, a.n, (uint4*)sl->d_halves.p);
-            d_items = (const uint8_t*)sl->d_halves.p;
-            nw = 4;
-        } else if (a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && (((uintptr_t)d_scalars & 15) == 0)) {
-            nw = 8;
-        }
-        const size_t hist_lds = (size_t)(g.merged ? g.W : g.Wl) * sg.cb * 4;   // one row per window
-        if (hist_lds > 64 * 1024) {
-            msm_set_err(ctx, "too many windows x coarse bins for the histogram kernel (use a wider window)");
-            return MSM_AMD_EINVAL;
-        }
-        // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
-        if (!sl->binhist_zero.holds(sl->d_binhist)) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
-        sl->binhist_zero.clear();   // until this submission has got as far as k_bin_scan
-        HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
+    split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
+    w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
+    split = w_split * g.half;                                               // first bucket of the second group
+    return 0;
+}
+
+// ---- stages 1-3: the bucket sort (sort_kernels.hpp) on the sort stream
+template <class F>
+int MsmCall<F>::sort() {
+
+    // ---- 1. populations of the (owned window, coarse bin) pairs -- digits recomputed from the scalars, never stored
+    SortGeom sg;
+    // fine key: 8 bits up to c = 17 (at c = 16: 128 coarse bins, spans of n / 128 entries -- one workgroup reads a span once up
+    // to n = 2^20 -- and runs of tile / 128 entries in the partition), then 8 coarse bits and the rest fine
+    sg.fbits = g.c - 1 <= 16u ? std::min(g.c - 1, 8u) : g.c - 1 - 8u;
+    sg.cbits = g.c - 1 - sg.fbits;
+    sg.cb = 1u << sg.cbits;
+    sg.nbins = g.Wl * sg.cb;
+    // 4-byte partition entries {fine key | sign | index} at every size: the index field takes what the fine key and the sign leave
+    // of 32 bits; wider indices (n > 2^23 at c = 16, the W x n table indices of prepared bases) put their HIGH bits into the bin --
+    // S sub-bins per (window, coarse bin), see SortGeom
+    const uint64_t max_index = g.merged ? (uint64_t)g.W * g.stride : (uint64_t)nv;
+    sg.idxbits = 1;
+    while ((1ull << sg.idxbits) < max_index) ++sg.idxbits;
+    sg.idxbits = std::min(sg.idxbits, 31u - sg.fbits);
+    sg.S = (uint32_t)((max_index + (1ull << sg.idxbits) - 1) >> sg.idxbits);
+    if (sg.S == 0) sg.S = 1;
+    if (sg.S > 2048u) {
+        msm_set_err(ctx, "too many points for one pass of the sort (index slices > 2048): fewer points per call");
+        return MSM_AMD_EINVAL;
+    }
+    const size_t nsub = (size_t)sg.nbins * sg.S;   // bins the partition scatters into
+    // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
+    // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
+    // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
+    // 100 KB of LDS has to wait for a whole CU to drain of the long-running accumulation waves of the calls already in flight: with
+    // another call pending the small tiles give the better THROUGHPUT up to n = 2^22 (n = 2^20: 2.59-2.60 against 2.62-2.63 ms per
+    // MSM, 2^22: 10.80 against 10.95; equal from 2^24), and for the ranks of a many-way shard, which keep four calls in flight, at
+    // every size (8 ranks: n = 2^20 0.74 -> 0.70 ms per call, 2^22 2.19 -> 2.00, 2^26 24.7 -> 24.2; 2 % the other way at 4 ranks).
+    const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
+    const uint32_t tile = wide ? 4096u : 1024u;
+    const uint32_t ntile = (nv + tile - 1) / tile;
+    // chunks of the spans that are cut up (k_big_*): 8192 entries for 1024-lane workgroups on an idle chip, 4096 for 256-lane ones
+    // while other calls are in flight (sort_kernels.hpp)
+    // (measured, ms per MSM with two calls in flight, small | large chunks: n = 2^22 10.74 | 10.89, prepared 9.14 | 9.26, 2^23 19.32 | 19.36,
+    // 2^24 36.9 | 36.5, profiles/r03_chunk_mode.txt)
+    const bool small_chunks = ctx->chunk_mode ? ctx->chunk_mode == 1 : (others_pending && a.n < (1u << 24));
+    const uint32_t chunk = small_chunks ? (uint32_t)BIG_CHUNK_SMALL : (uint32_t)BIG_CHUNK;
+    const size_t max_chunks = ((size_t)g.Wl * nve) / chunk + sg.nbins + 1;
+    if (int rc = ensure(ctx, sl->d_tmp, (size_t)g.Wl * nve * 4)) return rc;
+    // (a buffer that grows may come back at the same address: "known to be zero" is keyed on the buffer's allocation count as
+    // well, ZeroMark in engine_ctx.hpp)
+    if (int rc = ensure(ctx, sl->d_binhist, nsub * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_binstart, (nsub + 1) * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_bincur, nsub * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_desc, max_chunks * 8)) return rc;
+    if (int rc = ensure(ctx, sl->d_bcursor, (size_t)NB * 4)) return rc;
+    uint32_t* binhist = (uint32_t*)sl->d_binhist.p;
+    uint32_t* binstart = (uint32_t*)sl->d_binstart.p;
+    uint32_t* bincur = (uint32_t*)sl->d_bincur.p;
+    uint32_t* cpre = (uint32_t*)sl->d_cpre.p;
+    uint2* desc = (uint2*)sl->d_desc.p;
+    uint32_t* bcursor = (uint32_t*)sl->d_bcursor.p;
+    // where the digits come from: 0 = any scalar size / bit range (bits read from memory per window), 8 = whole 32-byte scalars in
+    // registers, 4 = the 16-byte halves of the GLV schedule
+    const uint8_t* d_items = d_scalars;
+    int nw = 0;
+    if (use_glv) {
+        if (int rc = ensure(ctx, sl->d_halves, (size_t)nv * 16)) return rc;
+        k_glv_halves<<<nblk, 256, 0, st>>>(d_scalars, a.n, (uint4*)sl->d_halves.p);
+        d_items = (const uint8_t*)sl->d_halves.p;
+        nw = 4;
+    } else if (a.scalar_size == 32 && g.bit_lo == 0 && g.nbits == 256 && (((uintptr_t)d_scalars & 15) == 0)) {
+        nw = 8;
+    }
+    const size_t hist_lds = (size_t)(g.merged ? g.W : g.Wl) * sg.cb * 4;   // one row per window
+    if (hist_lds > 64 * 1024) {
+        msm_set_err(ctx, "too many windows x coarse bins for the histogram kernel (use a wider window)");
+        return MSM_AMD_EINVAL;
+    }
+    // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
+    if (!sl->binhist_zero.holds(sl->d_binhist)) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
+    sl->binhist_zero.clear();   // until this submission has got as far as k_bin_scan
+    HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
 #define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist, (uint32_t*)sl->d_flags.p)
-        if (wide) {
-            if (nw == 8) MSM_TILE_HIST(8, 1024);
-            else if (nw == 4) MSM_TILE_HIST(4, 1024);
-            else MSM_TILE_HIST(0, 1024);
-        } else {
-            if (nw == 8) MSM_TILE_HIST(8, 256);
-            else if (nw == 4) MSM_TILE_HIST(4, 256);
-            else MSM_TILE_HIST(0, 256);
-        }
+    if (wide) {
+        if (nw == 8) MSM_TILE_HIST(8, 1024);
+        else if (nw == 4) MSM_TILE_HIST(4, 1024);
+        else MSM_TILE_HIST(0, 1024);
+    } else {
+        if (nw == 8) MSM_TILE_HIST(8, 256);
+        else if (nw == 4) MSM_TILE_HIST(4, 256);
+        else MSM_TILE_HIST(0, 256);
+    }
 #undef MSM_TILE_HIST
-        HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
-        // ---- 2. bin starts
-        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, sg.S, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
-        sl->binhist_zero.set(sl->d_binhist);
-        HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
-        // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
-        // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
-        // 8-byte ones; the CU has 160 KB and hosts one 1024-lane workgroup)
+    HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
+    // ---- 2. bin starts
+    k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, sg.S, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
+    sl->binhist_zero.set(sl->d_binhist);
+    HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
+    // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
+    // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
+    // 8-byte ones; the CU has 160 KB and hosts one 1024-lane workgroup)
 #define MSM_TILE_SCATTER(NW, BL, E, GW)                                                                                              \
-    do {                                                                                                                             \
-        constexpr size_t lds_ = tile_scatter_lds<E>(4 * BL, GW, BL);                                                                  \
-        if (lds_ > 64 * 1024)                                                                                                         \
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<NW, 4, BL, E, GW>),                         \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                                  \
-        k_tile_scatter<NW, 4, BL, E, GW><<<ntile, BL, lds_, st>>>(d_items, g, sg, bincur, (E*)sl->d_tmp.p);                           \
-    } while (0)
+do {                                                                                                                             \
+    constexpr size_t lds_ = tile_scatter_lds<E>(4 * BL, GW, BL);                                                                  \
+    if (lds_ > 64 * 1024)                                                                                                         \
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<NW, 4, BL, E, GW>),                         \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_));                                  \
+    k_tile_scatter<NW, 4, BL, E, GW><<<ntile, BL, lds_, st>>>(d_items, g, sg, bincur, (E*)sl->d_tmp.p);                           \
+} while (0)
 #define MSM_TILE_SCATTER_E(NW, BL)          \
-    do {                                    \
-        MSM_TILE_SCATTER(NW, BL, uint32_t, 4);          \
-    } while (0)
-        if (wide) {
-            if (nw == 8) MSM_TILE_SCATTER_E(8, 1024);
-            else if (nw == 4) MSM_TILE_SCATTER_E(4, 1024);
-            else MSM_TILE_SCATTER_E(0, 1024);
-        } else {
-            if (nw == 8) MSM_TILE_SCATTER_E(8, 256);
-            else if (nw == 4) MSM_TILE_SCATTER_E(4, 256);
-            else MSM_TILE_SCATTER_E(0, 256);
-        }
+do {                                    \
+    MSM_TILE_SCATTER(NW, BL, uint32_t, 4);          \
+} while (0)
+    if (wide) {
+        if (nw == 8) MSM_TILE_SCATTER_E(8, 1024);
+        else if (nw == 4) MSM_TILE_SCATTER_E(4, 1024);
+        else MSM_TILE_SCATTER_E(0, 1024);
+    } else {
+        if (nw == 8) MSM_TILE_SCATTER_E(8, 256);
+        else if (nw == 4) MSM_TILE_SCATTER_E(4, 256);
+        else MSM_TILE_SCATTER_E(0, 256);
+    }
 #undef MSM_TILE_SCATTER_E
 #undef MSM_TILE_SCATTER
-        const uint32_t nf = 1u << sg.fbits;
-        const size_t bnd_lds = sg.S > 1 ? ((size_t)sg.S + 1) * 4 : 0;   // sub-bin boundaries of one span
-        const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * chunk) * 4 + bnd_lds;
-        // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
-        // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
-        // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
-        // (a prepared table's windows all fill the bucket set evenly: no partly used top window)
-        const uint32_t tb = (g.merged || g.ns != g.W) ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
-        const uint64_t mean_span = (uint64_t)nve / sg.cb;
-        const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
-        if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-        }
-        if (!expect_long || ctx->sort_big == 2) {
-            k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-        } else {
-            if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 1024, BIG_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-                HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-            }
-            const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
-            HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
-            k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, chunk, cpre);
-            k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, chunk, desc);
-            k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
-            k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, chunk, count);
-            k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
-            // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
-            const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
-            if (small_chunks) {
-                // (256-lane workgroups: several per CU, so the grid is the number of chunks, not one resident wave per CU)
-                const uint32_t grid_s = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 2048);
-                k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL><<<grid_s, 256, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
-            } else {
-                k_big_scatter<uint32_t, 1024, BIG_CHUNK><<<bigs_grid, 1024, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
-            }
-        }
-        k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
-        k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
-        HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
+    const uint32_t nf = 1u << sg.fbits;
+    const size_t bnd_lds = sg.S > 1 ? ((size_t)sg.S + 1) * 4 : 0;   // sub-bin boundaries of one span
+    const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * chunk) * 4 + bnd_lds;
+    // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
+    // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
+    // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
+    // (a prepared table's windows all fill the bucket set evenly: no partly used top window)
+    const uint32_t tb = (g.merged || g.ns != g.W) ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
+    const uint64_t mean_span = (uint64_t)nve / sg.cb;
+    const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
+    if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
     }
+    if (!expect_long || ctx->sort_big == 2) {
+        k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+    } else {
+        if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 1024, BIG_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+        }
+        const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
+        HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
+        k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, chunk, cpre);
+        k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, chunk, desc);
+        k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, chunk, count);
+        k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
+        // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
+        const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
+        if (small_chunks) {
+            // (256-lane workgroups: several per CU, so the grid is the number of chunks, not one resident wave per CU)
+            const uint32_t grid_s = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 2048);
+            k_big_scatter<uint32_t, 256, BIG_CHUNK_SMALL><<<grid_s, 256, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+        } else {
+            k_big_scatter<uint32_t, 1024, BIG_CHUNK><<<bigs_grid, 1024, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
+        }
+    }
+    k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
+    k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
+    HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
+    return 0;
+}
+
+template <class F>
+int MsmCall<F>::accumulate() {
     // ---- 4. accumulate (stream A, after this call's sort and after the previous call's accumulation).
     // A SMALL accumulation (buckets for fewer than five waves per SIMD: few owned windows of a sharded call, small n) goes to the
     // slot's own stream instead and may overlap the accumulations of the other calls in flight: measured better or equal whenever
@@ -776,7 +616,7 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
         if (int rc = ensure(ctx, sl->d_slices, std::max((size_t)split * k_first, (size_t)(NB - split) * k_second) * BSZ)) return rc;
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
-    uint8_t* buckets = (uint8_t*)sl->d_buckets.p;
+    buckets = (uint8_t*)sl->d_buckets.p;
     // G1 has two builds of the accumulation kernels (bucket_kernels.hpp): the chained one when the launch puts at least two waves
     // on every SIMD, the two-chain one otherwise
     auto accumulate = [&](const uint32_t* ord, uint32_t nbk, uint32_t k) -> int {
@@ -809,6 +649,11 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     if (split < NB)
         if (int rc = accumulate(order + split, NB - split, k_second)) return rc;
     HIPCHK(ctx, hipEventRecord(sl->ev[5], st));
+    return 0;
+}
+
+template <class F>
+int MsmCall<F>::reduce() {
     // ---- 5. reduce (streams B/C: overlap the next call's, or the second group's, accumulation on stream A)
     hipStream_t sb = sl->stream_b;
     // buckets per lane: up to 8 (16 where a point takes two threads, so that the waves still fit one per SIMD) for a lone call (its reduction is on the critical path: short dependent chains, one wave on
@@ -1428,78 +1273,7 @@ int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
     return dispatch(ctx, curve, group, a, out_partial);
 }
 
-// ---- prepared bases --------------------------------------------------------------------------------------
-int msm_amd_prepare_bases(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, uint32_t n, uint32_t scalar_bits,
-                          msm_amd_bases** out) {
-    if (!ctx || !out) return MSM_AMD_EINVAL;
-    *out = nullptr;
-    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || !bases || n == 0 || scalar_bits > 512) {
-        msm_set_err(ctx, "prepare_bases: bad curve / group / bases / n / scalar_bits");
-        return MSM_AMD_EINVAL;
-    }
-    if ((flags & (MSM_AMD_DEVICE_PTRS | MSM_AMD_DEVICE_BASES)) && ((uintptr_t)bases & 15)) {
-        msm_set_err(ctx, "device bases pointer must be 16-byte aligned");
-        return MSM_AMD_EINVAL;
-    }
-    // 0: scalars reduced modulo the group order, what a prover's witness and quotient coefficients are (255 bits for BLS12-381, 254 for BN254)
-    if (scalar_bits == 0) scalar_bits = curve == MSM_AMD_BLS12381 ? 255 : 254;
-    msm_amd_bases* h = new (std::nothrow) msm_amd_bases();
-    if (!h) return MSM_AMD_ENOMEM;
-    h->ctx = ctx;
-    h->curve = curve;
-    h->group = group;
-    h->n = n;
-    h->scalar_bits = scalar_bits;
-    plan_prepared(n, scalar_bits, ctx->force_c >= 3 ? ctx->force_c : 0, &h->c, &h->W, &h->ns);
-    if (h->c == 0) {
-        delete h;
-        msm_set_err(ctx, "prepare_bases: windows x points of the table must stay below 2^31");
-        return MSM_AMD_EINVAL;
-    }
-    std::lock_guard<std::mutex> lk(ctx->mu);   // (uses stream S; no call may be submitted meanwhile)
-    int rc;
-    if (curve == MSM_AMD_BLS12381 && group == 1) rc = build_table<Fp<Bls12381Fp>>(ctx, h, bases, flags);
-    else if (curve == MSM_AMD_BLS12381) rc = build_table<Fp2<Bls12381Fp>>(ctx, h, bases, flags);
-    else if (group == 1) rc = build_table<Fp<Bn254Fp>>(ctx, h, bases, flags);
-    else rc = build_table<Fp2<Bn254Fp>>(ctx, h, bases, flags);
-    if (rc) {
-        if (h->table) (void)hipFree(h->table);
-        delete h;
-        return rc;
-    }
-    *out = h;
-    return 0;
-}
-
-int msm_amd_release_bases(msm_amd_ctx* ctx, msm_amd_bases* h) {
-    if (!ctx) return MSM_AMD_EINVAL;
-    if (!h) return 0;
-    if (h->ctx != ctx) {
-        msm_set_err(ctx, "release_bases: the handle belongs to another context");
-        return MSM_AMD_EINVAL;
-    }
-    if (h->in_flight.load() > 0) {
-        msm_set_err(ctx, "release_bases: calls on these bases are still in flight (wait for their tickets first)");
-        return MSM_AMD_EINVAL;
-    }
-    (void)hipSetDevice(ctx->device);
-    if (h->table) (void)hipFree(h->table);
-    delete h;
-    return 0;
-}
-
-int msm_amd_bases_info(const msm_amd_bases* h, uint32_t* out6, uint64_t* table_bytes) {
-    if (!h || !out6) return MSM_AMD_EINVAL;
-    out6[0] = h->n;
-    out6[1] = h->scalar_bits;
-    out6[2] = h->c;
-    out6[3] = h->W;
-    out6[4] = h->ns;
-    out6[5] = 1u << (h->c - 1);
-    if (table_bytes) *table_bytes = h->table_bytes;
-    return 0;
-}
-
+// ---- prepared bases: the table is built in prepared.hip; the calls on a handle are ordinary submissions ---------------------------
 static int prepared_args(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, RunArgs* a) {
     if (!ctx || !h) return MSM_AMD_EINVAL;
     if (h->ctx != ctx) {

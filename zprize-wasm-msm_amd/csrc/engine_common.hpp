@@ -37,6 +37,8 @@ MSM_D void store16(void* p, const T& t) {
     for (int k = 0; k < (int)(sizeof(T) / 16); ++k) s[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
 }
 
+constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 8 coarse + 12 fine bits of bucket index (the sort's two levels, sort_kernels.hpp)
+
 // Window geometry shared by host and kernels.
 struct Geom {
     uint32_t n;

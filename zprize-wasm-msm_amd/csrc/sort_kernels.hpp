@@ -33,7 +33,7 @@ namespace msm {
 constexpr int SORT_BLOCK = 256;
 constexpr int COARSE_MAX = 256;        // coarse bins per window (8 bits)
 constexpr int FINE_MAX_BITS = 12;      // fine buckets per coarse bin (4096)
-constexpr int MAX_WINDOW_BITS = 1 + 8 + FINE_MAX_BITS;   // sign + coarse + fine = 21
+static_assert(MAX_WINDOW_BITS == 1 + 8 + FINE_MAX_BITS, "sign + coarse + fine bits of a window (engine_common.hpp)");
 
 // Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
 MSM_D uint32_t scalar_bits(const uint8_t* scalars, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
