@@ -600,11 +600,14 @@ int MsmCall<F>::accumulate() {
         // top bit is clear.  Such buckets are many, equally long, and start first (population order): they are lanes like any other,
         // as long as their chain stays below the launch's own duration (cap: 80 % of a lane slot's share of the additions).
         auto bound = [](uint64_t d) { return (uint32_t)std::min<uint64_t>(d + 8u * (uint64_t)std::ceil(std::sqrt((double)d)) + 8u, 1u << 24); };
-        uint32_t seg_hi = bound(2ull * mean);
+        // Case (a) is not capped (round 3): the cap is about how long a chain may get, and twice the mean is where such buckets END --
+        // capping the segment length at 88 where they hold 64 +- 8 entries sent a few dozen of them per call through the tail kernels
+        // (BN254 G2 n = 2^20 with scalars below its 254-bit order: 4.41 ms per MSM against 3.87 with 255-bit scalars).
+        uint32_t seg_hi = 0;
         const uint32_t tb = even_layout ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
-        if (tb >= 12 && tb < g.c - 1) seg_hi = std::max(seg_hi, bound(2ull * (((uint64_t)nv + (1ull << tb) - 1) >> tb)));
+        if (tb >= 12 && tb < g.c - 1) seg_hi = bound(2ull * (((uint64_t)nv + (1ull << tb) - 1) >> tb));
         const uint32_t cap = (uint32_t)std::min<uint64_t>(((uint64_t)g.Wl * nve) / 245760u, 1u << 20);
-        seg = std::max(seg, std::min(seg_hi, cap));
+        seg = std::max(std::max(seg, bound(2ull * mean)), std::min(seg_hi, cap));
     }
     const uint32_t seg_min = (seg + std::max(k_first, k_second) - 1) / std::max(k_first, k_second);
     const size_t max_segs = (size_t)g.Wl * nve / seg_min + 1;
