@@ -47,6 +47,7 @@ static int (*p_conv[6])(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_
 static int (*p_glv_dec)(const uint8_t *, uint8_t *, uint32_t *);
 static int (*p_glv_endo)(const uint8_t *, uint32_t, uint8_t *);
 static int (*p_glv_pre)(msm_amd_ctx *, uint32_t, const void *, const void *, uint32_t, void *, void *);
+static int (*p_set_option)(msm_amd_ctx *, const char *, uint32_t);
 static int (*p_prepare_bases)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint32_t, msm_amd_bases **);
 static int (*p_release_bases)(msm_amd_ctx *, msm_amd_bases *);
 static int (*p_bases_info)(const msm_amd_bases *, uint32_t *, uint64_t *);
@@ -105,6 +106,7 @@ static const char *load_engine(void) {
     SYM(p_glv_dec, "msm_amd_glv_decompose_scalar")
     SYM(p_glv_endo, "msm_amd_glv_endomorphism")
     SYM(p_glv_pre, "msm_amd_glv_preprocess")
+    SYM(p_set_option, "msm_amd_set_option")
     SYM(p_prepare_bases, "msm_amd_prepare_bases")
     SYM(p_release_bases, "msm_amd_release_bases")
     SYM(p_bases_info, "msm_amd_bases_info")
@@ -200,6 +202,24 @@ static napi_value js_set_window_bits(napi_env env, napi_callback_info info) {
         return NULL;
     }
     if (p_set_window_bits((msm_amd_ctx *)ctx, c)) napi_throw_range_error(env, NULL, "window bits out of range");
+    return NULL;
+}
+
+/* setOption(ctx, name, value): msm_amd_set_option -- "slots" (calls in flight: promises beyond it wait), "window_bits", ... */
+static napi_value js_set_option(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    char name[64];
+    size_t len = 0;
+    uint32_t v;
+    if (argc < 3 || napi_get_value_external(env, argv[0], &ctx) != napi_ok ||
+        napi_get_value_string_utf8(env, argv[1], name, sizeof name, &len) != napi_ok || get_u32(env, argv[2], &v)) {
+        napi_throw_type_error(env, NULL, "setOption(ctx, name: string, value: uint32)");
+        return NULL;
+    }
+    if (p_set_option((msm_amd_ctx *)ctx, name, v)) napi_throw_range_error(env, NULL, p_last_error((msm_amd_ctx *)ctx));
     return NULL;
 }
 
@@ -967,6 +987,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"combine", NULL, js_combine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toMontgomery", NULL, js_to_mont, NULL, NULL, NULL, napi_enumerable, NULL},
         {"fromMontgomery", NULL, js_from_mont, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"setOption", NULL, js_set_option, NULL, NULL, NULL, napi_enumerable, NULL},
         {"prepareBases", NULL, js_prepare_bases, NULL, NULL, NULL, napi_enumerable, NULL},
         {"basesInfo", NULL, js_bases_info, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpPrepared", NULL, js_multiexp_prepared, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -123,6 +123,9 @@ function curve(curveName, opts) {
     const C = lookup(curveName);
     const ctx = context(opts && opts.device);
     const maxSlice = (opts && opts.maxSlice) || (1 << 22);
+    // opts.options = {name: value}: engine options (msm_amd_set_option), e.g. {slots: 4} -- how many calls may be in flight at once
+    // (unresolved promises beyond it wait inside the engine): two suit n >= 2^19, three or four n <= 2^18 (DESIGN.md section 5)
+    for (const [k, v] of Object.entries((opts && opts.options) || {})) native.setOption(ctx, k, v);
     const dist = opts && opts.dist;
     if (dist) native.distInit(ctx, dist.rank, dist.world, dist.id);
     const distQueue = [];
