@@ -128,7 +128,8 @@ int msm_amd_wait(msm_amd_ctx *ctx, uint64_t ticket, uint8_t *out);
  *                msm_amd_multiexp_prepared: MSM_AMD_DEVICE_PTRS (scalars resident).
  *   n            a call may use any prefix of the prepared points.
  * The asynchronous form returns a ticket for msm_amd_wait.  A handle is released with msm_amd_release_bases once no call on it is
- * in flight; it belongs to the context that prepared it.  Option "window_bits" (>= 3) at prepare time forces the table's window size. */
+ * in flight; it belongs to the context that prepared it (msm_amd_destroy frees the tables of handles never released -- the handles
+ * are invalid afterwards).  Option "window_bits" (>= 3) at prepare time forces the table's window size. */
 int msm_amd_prepare_bases(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, uint32_t n,
                           uint32_t scalar_bits, msm_amd_bases **out);
 int msm_amd_release_bases(msm_amd_ctx *ctx, msm_amd_bases *bases);

@@ -431,3 +431,19 @@ def test_index_slices_of_the_partition(eng, orc):
         eng.set_window_bits(0)
         eng.set_option("sort_big", 0)
         pts.free()
+
+
+def test_context_destruction_frees_unreleased_tables(orc):
+    """A handle the caller never released: msm_amd_destroy frees its table (the handle is invalid afterwards); a fresh context works."""
+    import msm_amd
+    curve, group, n = "bn128", 1, 3000
+    bases, scalars = gu.random_case(curve, group, "gpu:prep:leak", n)
+    O = orc.Oracle(curve, group)
+    exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+    for _ in range(2):
+        eng = msm_amd.Engine(0)
+        C = eng.curve(curve)
+        pb = C.prepare_bases(group, bases, n)
+        assert pb.multiexp(scalars) == exp
+        pb.handle = None          # forget it without releasing
+        eng.close()

@@ -1144,6 +1144,11 @@ void msm_amd_destroy(msm_amd_ctx* ctx) {
         for (auto& e : sl.ev)
             if (e) (void)hipEventDestroy(e);
     }
+    for (msm_amd_bases* h : ctx->prepared_handles) {   // tables the caller never released
+        if (h->table) (void)hipFree(h->table);
+        delete h;
+    }
+    ctx->prepared_handles.clear();
     if (ctx->stream_s) (void)hipStreamDestroy(ctx->stream_s);
     if (ctx->stream_s2) (void)hipStreamDestroy(ctx->stream_s2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

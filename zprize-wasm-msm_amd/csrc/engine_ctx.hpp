@@ -127,6 +127,7 @@ struct msm_amd_ctx {
     } dist;
     std::mutex dist_mu;
     std::condition_variable dist_cv;   // next_exchange moved on
+    std::vector<msm_amd_bases*> prepared_handles;   // handles this context has prepared and not released (guarded by mu): freed by msm_amd_destroy
     int even_windows = 1;              // option "even_windows": windows of c and c - 1 bits that tile the scalar exactly when c does not divide its width
     uint32_t dist_gw = 0;              // option "dist_gw": window groups of a sharded call (0 = chosen per call; must divide the world size)
     // Threads: submitting (GPU work is queued on shared streams) and collecting (host combine, shared timing fields) are

@@ -179,6 +179,7 @@ int msm_amd_prepare_bases(msm_amd_ctx* ctx, int curve, int group, uint32_t flags
         delete h;
         return rc;
     }
+    ctx->prepared_handles.push_back(h);
     *out = h;
     return 0;
 }
@@ -193,6 +194,11 @@ int msm_amd_release_bases(msm_amd_ctx* ctx, msm_amd_bases* h) {
     if (h->in_flight.load() > 0) {
         msm_set_err(ctx, "release_bases: calls on these bases are still in flight (wait for their tickets first)");
         return MSM_AMD_EINVAL;
+    }
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto& v = ctx->prepared_handles;
+        v.erase(std::remove(v.begin(), v.end(), h), v.end());
     }
     (void)hipSetDevice(ctx->device);
     if (h->table) (void)hipFree(h->table);

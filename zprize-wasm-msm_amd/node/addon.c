@@ -522,13 +522,14 @@ typedef struct {
     msm_amd_ctx *ctx;
     void *dev;
     size_t bytes;
+    napi_ref ref_ctx; /* keeps the context's external alive as long as the buffer */
 } bases_t;
 static void bases_finalize(napi_env env, void *data, void *hint) {
-    (void)env;
     (void)hint;
     bases_t *b = (bases_t *)data;
     if (b) {
         if (b->dev && p_dev_free) p_dev_free(b->ctx, b->dev);
+        if (b->ref_ctx) napi_delete_reference(env, b->ref_ctx);
         free(b);
     }
 }
@@ -553,6 +554,7 @@ static napi_value js_upload_bases(napi_env env, napi_callback_info info) {
         free(b);
         return NULL;
     }
+    napi_create_reference(env, argv[0], 1, &b->ref_ctx);
     napi_value ext;
     NAPI_OK(napi_create_external(env, b, bases_finalize, NULL, &ext));
     return ext;
@@ -599,13 +601,14 @@ typedef struct {
     msm_amd_bases *h;
     int curve, group;
     uint32_t n;
+    napi_ref ref_ctx; /* the context's external: it must outlive the handle (finalisers run in no particular order) */
 } prepared_t;
 static void prepared_finalize(napi_env env, void *data, void *hint) {
-    (void)env;
     (void)hint;
     prepared_t *b = (prepared_t *)data;
     if (b) {
         if (b->h && p_release_bases) p_release_bases(b->ctx, b->h);
+        if (b->ref_ctx) napi_delete_reference(env, b->ref_ctx);
         free(b);
     }
 }
@@ -640,6 +643,7 @@ static napi_value js_prepare_bases(napi_env env, napi_callback_info info) {
         free(b);
         return NULL;
     }
+    napi_create_reference(env, argv[0], 1, &b->ref_ctx);
     napi_value ext;
     NAPI_OK(napi_create_external(env, b, prepared_finalize, NULL, &ext));
     return ext;
