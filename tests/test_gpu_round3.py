@@ -447,3 +447,34 @@ def test_context_destruction_frees_unreleased_tables(orc):
         assert pb.multiexp(scalars) == exp
         pb.handle = None          # forget it without releasing
         eng.close()
+
+
+def test_glv_schedule_right_after_skewed_calls(orc):
+    """The skew hint switches 16-bit windows to the even layout (1 signed + 16 unsigned windows: no carry window for scalars that use
+    all 256 bits).  The GLV schedule keeps its own eight signed 16-bit windows over the 128-bit halves whatever the hint says (a first
+    version left it with the even layout's signed-window count: wrong sums, caught by the order of the tests in a shared context)."""
+    import msm_amd
+    curve, group = "bls12381", 1
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        n = 20000
+        bases, _ = gu.random_case(curve, group, "gpu:glvskew", n)
+        k = ((1 << 256) - 12345).to_bytes(32, "little")
+        C.g1m_multiexpAffine(bases, k * n, 32, n)                       # all scalars equal and 256 bits wide: sets the hint
+        full = b"".join((((1 << 255) | (i * 0x9E3779B97F4A7C15)) % (1 << 256)).to_bytes(32, "little") for i in range(n))
+        exp = O.normalize(O.multiexp_affine(bases, full, 32, n))
+        assert C.g1m_multiexpAffine(bases, full, 32, n) == exp          # 256-bit scalars on the even layout chosen under the hint
+        assert (eng.geometry()["c"], eng.geometry()["windows"]) in ((14, 19), (16, 17))
+        eng.set_option("glv", 2)
+        m = 4500
+        b2, s2 = gu.random_case(curve, group, "gpu:glvskew:2", m)
+        assert C.g1m_multiexpAffine(b2, s2, 32, m) == O.normalize(O.multiexp_affine(b2, s2, 32, m))
+        assert eng.geometry()["windows"] == 8
+        eng.set_option("glv", 0)
+        eng.set_window_bits(16)
+        assert C.g1m_multiexpAffine(b2, s2, 32, m) == O.normalize(O.multiexp_affine(b2, s2, 32, m))
+        assert eng.geometry()["windows"] == 17                          # hint still on: 1 signed + 16 unsigned windows
+    finally:
+        eng.close()

@@ -304,6 +304,7 @@ int MsmCall<F>::plan() {
         g.n = nv;
         g.nbits = 128;
         g.W = 8;
+        g.ns = 8;   // eight signed 16-bit windows over the 128-bit halves, whatever layout the 256-bit scalar would have taken
     }
     g.Wl = 0;
     for (uint32_t w = 0; w < g.W; ++w)
