@@ -196,6 +196,8 @@ def main():
     # the same slice.  MSM_BENCH_GW forces the number of window groups (gw = world: windows only, every rank holds everything).
     if os.environ.get("MSM_BENCH_GW"):
         eng.set_option("dist_gw", int(os.environ["MSM_BENCH_GW"]))
+    if args.prepared and sharded:
+        eng.set_option("dist_gw", 1)      # prepared tables in a group: the points are cut along the points only, one table per rank
     plan = eng.dist_plan(args.curve, g, 32, n, world, rank) if sharded else {"gp": 1, "gw": 1, "first": 0, "count": n}
     first, count = plan["first"], plan["count"]
     pts = C.gen_points(g, 0xC0FFEE02, count, first)
@@ -205,10 +207,10 @@ def main():
 
     prep = None
     if args.prepared:
-        if sharded or args.host_buffers:
-            sys.exit("bench.py: --prepared is a one-GPU, resident-inputs mode")
+        if args.host_buffers:
+            sys.exit("bench.py: --prepared is a resident-inputs mode")
         t_prep = time.perf_counter()
-        prep = C.prepare_bases(g, pts, n)
+        prep = C.prepare_bases(g, pts, count)          # (N > 1: the table of this rank's slice)
         torch.cuda.synchronize()
         t_prep = time.perf_counter() - t_prep
     h_pts = h_sc = None
@@ -252,9 +254,13 @@ def main():
                 if rank == 0:
                     print("bench.py: exchanging through torch.distributed on every rank", file=sys.stderr)
     cabi = bool(exchange and exchange.startswith("C ABI"))
+    if cabi and args.prepared:
+        exchange = "C ABI: msm_amd_multiexp_dist_prepared_async / msm_amd_dist_wait (every rank the prepared table of its slice; ncclAllGather on the engine's own communicator)"
     gw = plan["gw"]
 
     def step():
+        if cabi and prep is not None:
+            return prep.multiexp_dist(d_scalars)
         if cabi:
             return C.multiexp_dist_local(g, pts, d_scalars, 32, count, n)
         if args.host_buffers:
@@ -330,7 +336,11 @@ def main():
             # `depth` steps in flight: the bucket reduction of step i (stream B) overlaps the sort + accumulation of step i+1 (stream A)
             inflight = []
             for _ in range(steps):
-                if prep is not None:
+                if prep is not None and sharded:
+                    if not cabi:
+                        sys.exit("bench.py: --prepared with N > 1 needs the C-ABI exchange (msm_amd_dist_init failed)")
+                    inflight.append(prep.multiexp_dist_async(d_scalars))
+                elif prep is not None:
                     inflight.append(prep.multiexp_async(d_scalars))
                 elif not sharded:
                     inflight.append(C.multiexp_async(g, pts, d_scalars, 32, n))

@@ -194,6 +194,13 @@ int msm_amd_multiexp_dist_local(msm_amd_ctx *ctx, int curve, int group, uint32_t
 int msm_amd_multiexp_dist_local_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases_local,
                                       const void *scalars_local, uint32_t scalar_size, uint32_t n_local, uint32_t n_total,
                                       uint64_t *ticket);
+/* prepared bases in a group: the points cut along the points only, every rank holding the PREPARED table of its own slice (the slices
+ * need not be equal); this rank's part is a whole msm_amd_multiexp_prepared over its n_local points.  Collect the asynchronous form with
+ * msm_amd_dist_wait(ctx, curve, group of the table, ticket, out). */
+int msm_amd_multiexp_dist_prepared(msm_amd_ctx *ctx, msm_amd_bases *local_table, uint32_t flags, const void *scalars_local,
+                                   uint32_t scalar_size, uint32_t n_local, uint8_t *out);
+int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx *ctx, msm_amd_bases *local_table, uint32_t flags, const void *scalars_local,
+                                         uint32_t scalar_size, uint32_t n_local, uint64_t *ticket);
 int msm_amd_dist_wait(msm_amd_ctx *ctx, int curve, int group, uint64_t ticket, uint8_t *out);
 
 /* ---- reference-named wrappers (host pointers) ------------------------------------------------- */

@@ -478,3 +478,38 @@ def test_glv_schedule_right_after_skewed_calls(orc):
         assert eng.geometry()["windows"] == 17                          # hint still on: 1 signed + 16 unsigned windows
     finally:
         eng.close()
+
+
+def test_prepared_tables_inside_a_group(orc):
+    """msm_amd_multiexp_dist_prepared: every rank holds the prepared table of its own slice and its part of a call is a whole prepared
+    MSM of that slice (a group of one here: the slice is everything).  Prepared and ordinary calls of a group share the sequence of
+    exchanges."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 70000
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("slots", 3)
+        eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, "gpu:prepdist", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        pb = C.prepare_bases(group, bases, n)
+        try:
+            assert pb.multiexp_dist(scalars) == exp
+            t = [pb.multiexp_dist_async(scalars), C.multiexp_dist_async(group, bases, scalars, 32, n), pb.multiexp_dist_async(scalars, 32, 1000)]
+            e1000 = O.normalize(O.multiexp_affine(bases[:96 * 1000], scalars[:32 * 1000], 32, 1000))
+            assert t[2].wait.__self__ is t[2]
+            got = [None] * 3
+            for k in (0, 1, 2):
+                got[k] = t[k].wait()
+            assert got == [exp, exp, e1000]
+            wide = bytearray(scalars)
+            wide[31] |= 0x80                                      # a scalar wider than the table: this rank's error, the sequence goes on
+            with pytest.raises(msm_amd.MsmAmdError, match="prepared for"):
+                pb.multiexp_dist(bytes(wide))
+            assert pb.multiexp_dist(scalars) == exp
+        finally:
+            pb.release()
+    finally:
+        eng.close()

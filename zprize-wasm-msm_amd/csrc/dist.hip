@@ -247,7 +247,8 @@ namespace {
 // group's sequence of exchanges.  A part that cannot be queued (bad argument, HIP failure, no free slot) still gets a ticket and a
 // place: the other ranks WILL enter the collective of this call, so this rank has to as well (with a failure mark, see dist_wait).
 int dist_submit(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size, uint32_t count,
-                uint32_t w, uint32_t gw, uint64_t* ticket, int refused_rc = 0, const std::string& refused_why = std::string()) {
+                uint32_t w, uint32_t gw, uint64_t* ticket, int refused_rc = 0, const std::string& refused_why = std::string(),
+                msm_amd_bases* prepared = nullptr) {
     // (dist_mu is held across the submission so that two threads cannot take sequence numbers in one order and engine tickets in
     // the other; the submission itself only queues GPU work)
     std::lock_guard<std::mutex> dl(ctx->dist_mu);
@@ -258,7 +259,9 @@ int dist_submit(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const vo
         rec.rc = refused_rc;
         rec.err = refused_why;
     } else {
-        rec.rc = msm_amd_multiexp_shard_async(ctx, curve, group, flags, bases, scalars, scalar_size, count, w, gw, &rec.engine_ticket);
+        // (a prepared table holds every window of its points: such a part is a whole MSM of this rank's points)
+        rec.rc = prepared ? msm_amd_multiexp_prepared_async(ctx, prepared, flags, scalars, scalar_size, count, &rec.engine_ticket)
+                          : msm_amd_multiexp_shard_async(ctx, curve, group, flags, bases, scalars, scalar_size, count, w, gw, &rec.engine_ticket);
         if (rec.rc) rec.err = msm_amd_last_error(ctx);
     }
     rec.seq = ctx->dist.next_seq++;
@@ -416,6 +419,33 @@ int msm_amd_multiexp_dist(msm_amd_ctx* ctx, int curve, int group, uint32_t flags
                           uint32_t n, uint8_t* out) {
     uint64_t t = 0;
     if (int rc = msm_amd_multiexp_dist_async(ctx, curve, group, flags, bases, scalars, scalar_size, n, &t)) return rc;
+    return msm_amd_dist_wait(ctx, curve, group, t, out);
+}
+
+// The points of the group cut along the points only, every rank holding the PREPARED table of its own slice (msm_amd_prepare_bases on
+// whatever slice the host gave it: the slices need not be equal): this rank's part is msm_amd_multiexp_prepared over its n_local points.
+int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* local_table, uint32_t flags, const void* scalars_local, uint32_t scalar_size,
+                                         uint32_t n_local, uint64_t* ticket) {
+    if (!ctx || !ticket) return MSM_AMD_EINVAL;
+    if (!ctx->dist.comm) {
+        msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
+        return MSM_AMD_EINVAL;
+    }
+    uint32_t info[6];
+    if (!local_table || msm_amd_bases_info(local_table, info, nullptr)) {
+        msm_set_err(ctx, "multiexp_dist_prepared: no table");
+        return MSM_AMD_EINVAL;
+    }
+    int curve = 0, group = 0;
+    msm_bases_kind(local_table, &curve, &group);
+    return dist_submit(ctx, curve, group, flags, nullptr, scalars_local, scalar_size, n_local, 0, 1, ticket, 0, std::string(), local_table);
+}
+int msm_amd_multiexp_dist_prepared(msm_amd_ctx* ctx, msm_amd_bases* local_table, uint32_t flags, const void* scalars_local, uint32_t scalar_size,
+                                   uint32_t n_local, uint8_t* out) {
+    uint64_t t = 0;
+    if (int rc = msm_amd_multiexp_dist_prepared_async(ctx, local_table, flags, scalars_local, scalar_size, n_local, &t)) return rc;
+    int curve = 0, group = 0;
+    msm_bases_kind(local_table, &curve, &group);
     return msm_amd_dist_wait(ctx, curve, group, t, out);
 }
 

@@ -102,6 +102,11 @@ struct msm_amd_bases {
     std::atomic<int> in_flight{0};   // calls submitted and not yet collected (release refuses while > 0)
 };
 
+inline void msm_bases_kind(const msm_amd_bases* h, int* curve, int* group) {
+    *curve = h->curve;
+    *group = h->group;
+}
+
 struct msm_amd_ctx {
     int device = 0;
     // multi-GPU group this context belongs to (dist.hip): RCCL communicator + staging for the exchange of the window partials

@@ -95,6 +95,8 @@ def load_library(path=None):
     L.msm_amd_bases_info.argtypes = [vp, c.POINTER(u32), c.POINTER(c.c_uint64)]
     L.msm_amd_multiexp_prepared.argtypes = [vp, vp, u32, vp, u32, u32, u8p]
     L.msm_amd_multiexp_prepared_async.argtypes = [vp, vp, u32, vp, u32, u32, c.POINTER(c.c_uint64)]
+    L.msm_amd_multiexp_dist_prepared.argtypes = [vp, vp, u32, vp, u32, u32, u8p]
+    L.msm_amd_multiexp_dist_prepared_async.argtypes = [vp, vp, u32, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_normalize.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_to_affine.argtypes = [c.c_int, c.c_int, vp, u8p]
     L.msm_amd_eq.argtypes = [c.c_int, c.c_int, vp, vp]
@@ -300,6 +302,19 @@ class PreparedBases:
         eng._chk(eng.L.msm_amd_multiexp_prepared_async(eng.ctx, self.handle, FLAG_DEVICE if dev_s else 0, ps, scalar_size,
                                                        self.n if n is None else n, ctypes.byref(t)))
         return Ticket(self.curve, self.group, t.value, (ks, self))
+
+    def multiexp_dist_async(self, scalars_local, scalar_size=32, n=None):
+        """msm_amd_multiexp_dist_prepared_async: this table holds this rank's slice of a group's points; the ticket's wait() exchanges the
+        partials of all ranks and returns the sum (Engine.dist_init first)."""
+        ps, dev_s, ks = _as_ptr(scalars_local)
+        t = ctypes.c_uint64()
+        eng = self.curve.eng
+        eng._chk(eng.L.msm_amd_multiexp_dist_prepared_async(eng.ctx, self.handle, FLAG_DEVICE if dev_s else 0, ps, scalar_size,
+                                                            self.n if n is None else n, ctypes.byref(t)))
+        return DistTicket(self.curve, self.group, t.value, (ks, self))
+
+    def multiexp_dist(self, scalars_local, scalar_size=32, n=None):
+        return self.multiexp_dist_async(scalars_local, scalar_size, n).wait()
 
     def release(self):
         if self.handle:
