@@ -513,3 +513,68 @@ def test_prepared_tables_inside_a_group(orc):
             pb.release()
     finally:
         eng.close()
+
+
+def test_randomised_round3_configurations(eng, orc):
+    """60 seeded random combinations of what round 3 added: windows of even width on / off, any window size, scalar sizes whose bit
+    count the window does or does not divide, prepared tables with a random declared width and forced window size, hybrid splits of
+    2 .. 8 ranks summed on this GPU, the forms of the fine sort and of its chunks -- each against the oracle."""
+    import random
+    import msm_amd
+    from msm_amd import dist as mdist
+    rnd = random.Random(20261004)
+    try:
+        for it in range(60):
+            curve = rnd.choice(["bls12381", "bn128"])
+            group = 1 if rnd.random() < 0.75 else 2
+            n = rnd.choice([1, 3, 17, 100, 513, 2049, 6000, 20000] if group == 1 else [1, 9, 130, 700])
+            ss = rnd.choice([32, 32, 32, 31, 17, 8, 2, 33, 64])
+            C = eng.curve(curve)
+            O = orc.Oracle(curve, group)
+            asz = C.affine_bytes(group)
+            bases, _ = gu.random_case(curve, group, f"gpu:rand3:{it}", n)
+            raw = gu.stream(f"gpu:rand3:{it}:s", n * ss)
+            # now and then every scalar with all its bits set in the top byte (full-width values) or only a few low bytes in use
+            kind = rnd.choice(["uniform", "uniform", "full", "short"])
+            sc = bytearray(raw)
+            if kind == "full":
+                for i in range(n):
+                    sc[i * ss + ss - 1] |= 0x80
+            elif kind == "short":
+                for i in range(n):
+                    sc[i * ss + max(1, ss // 2):(i + 1) * ss] = bytes(ss - max(1, ss // 2))
+            scalars = bytes(sc)
+            c = rnd.choice([0, 0, 3, 5, 9, 12, 13, 14, 15, 17, 19, 20, 21])
+            eng.set_window_bits(c)
+            eng.set_option("even_windows", rnd.choice([1, 1, 1, 0]))
+            eng.set_option("sort_big", rnd.choice([0, 0, 1, 2]))
+            eng.set_option("chunk_mode", rnd.choice([0, 1, 2]))
+            exp = gu.canon(curve, group, O.normalize(O.multiexp_affine(bases, scalars, ss, n)), O.zero())
+            mode = rnd.choice(["full", "prepared", "prepared", "hybrid"])
+            tag = (it, curve, group, n, ss, kind, c, mode)
+            if mode == "full":
+                got = C._multiexp(group, 0, bases, scalars, ss, n)
+            elif mode == "prepared":
+                bits = rnd.choice([8 * ss, 8 * ss, min(8 * ss + 5, 512)])
+                pb = C.prepare_bases(group, bases, n, scalar_bits=bits)
+                try:
+                    m = n if rnd.random() < 0.7 else max(1, n // 2)
+                    got = pb.multiexp(scalars[:m * ss], ss, m)
+                    if m != n:
+                        exp = gu.canon(curve, group, O.normalize(O.multiexp_affine(bases[:m * asz], scalars[:m * ss], ss, m)), O.zero())
+                finally:
+                    pb.release()
+            else:
+                world = rnd.choice([2, 3, 4, 6, 8])
+                gw = rnd.choice([w for w in range(1, world + 1) if world % w == 0])
+                parts = []
+                for r in range(world):
+                    first, count = mdist.slice_of(n, world // gw, r // gw)
+                    parts.append(C.multiexp_shard(group, bases[first * asz:(first + count) * asz], scalars[first * ss:(first + count) * ss], ss, count, r % gw, gw))
+                got = msm_amd.combine(curve, group, b"".join(parts))
+            assert got == exp, (tag, eng.geometry())
+    finally:
+        eng.set_window_bits(0)
+        eng.set_option("even_windows", 1)
+        eng.set_option("sort_big", 0)
+        eng.set_option("chunk_mode", 0)
