@@ -64,8 +64,8 @@ enum {
 enum {
     MSM_AMD_OK = 0,
     MSM_AMD_EINVAL = -1,   /* bad argument (null pointer, scalar_size out of range, bad curve/group, misaligned device pointer) */
-    MSM_AMD_EHIP = -2,     /* HIP runtime failure (no GPU, out of memory, launch failure) */
-    MSM_AMD_ENOMEM = -3,
+    MSM_AMD_EHIP = -2,     /* HIP runtime failure (no GPU, launch failure, a failed copy) */
+    MSM_AMD_ENOMEM = -3,   /* out of memory, host or device (the error text names the allocation: scratch of a call, a prepared table) */
     MSM_AMD_EPEER = -4     /* multi-GPU call: another rank of the group failed its part (this rank's part was fine) */
 };
 

@@ -131,6 +131,15 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
     }
 }
 
+// this context's place in its group, read under dist_mu (dist_init / dist_destroy write it under the same lock); false = no group
+static bool dist_group(const msm_amd_ctx* ctx, int* rank, int* world) {
+    std::lock_guard<std::mutex> dl(ctx->dist_mu);
+    if (!ctx->dist.comm) return false;
+    *rank = ctx->dist.rank;
+    *world = ctx->dist.world;
+    return true;
+}
+
 extern "C" {
 
 int msm_amd_dist_unique_id(uint8_t* out128) {
@@ -218,8 +227,7 @@ int msm_amd_dist_destroy(msm_amd_ctx* ctx) {
 
 int msm_amd_dist_info(const msm_amd_ctx* ctx, int* rank, int* world) {
     if (!ctx || !rank || !world) return MSM_AMD_EINVAL;
-    *rank = ctx->dist.comm ? ctx->dist.rank : 0;
-    *world = ctx->dist.comm ? ctx->dist.world : 0;
+    if (!dist_group(ctx, rank, world)) *rank = *world = 0;
     return 0;
 }
 
@@ -229,9 +237,10 @@ int msm_amd_dist_plan(const msm_amd_ctx* ctx, int curve, int group, uint32_t sca
                       uint32_t* gw, uint32_t* first, uint32_t* count) {
     if (!ctx || !gp || !gw || !first || !count) return MSM_AMD_EINVAL;
     if (world == 0) {
-        if (!ctx->dist.comm) return MSM_AMD_EINVAL;
-        world = (uint32_t)ctx->dist.world;
-        rank = (uint32_t)ctx->dist.rank;
+        int r = 0, w = 0;
+        if (!dist_group(ctx, &r, &w)) return MSM_AMD_EINVAL;
+        world = (uint32_t)w;
+        rank = (uint32_t)r;
     }
     if (rank >= world || scalar_size < 1 || scalar_size > 64) return MSM_AMD_EINVAL;
     msm_dist_split(ctx, curve, group, scalar_size, n, world, gp, gw);
@@ -279,7 +288,8 @@ extern "C" {
 int msm_amd_multiexp_dist_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
                                 uint32_t n, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
-    if (!ctx->dist.comm) {
+    int my_rank = 0, world = 0;
+    if (!dist_group(ctx, &my_rank, &world)) {
         msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
         return MSM_AMD_EINVAL;
     }
@@ -288,19 +298,20 @@ int msm_amd_multiexp_dist_async(msm_amd_ctx* ctx, int curve, int group, uint32_t
         return MSM_AMD_EINVAL;   // (the same on every rank: nothing was queued anywhere)
     }
     uint32_t gp, gw, first, count;
-    msm_dist_split(ctx, curve, group, scalar_size, n, (uint32_t)ctx->dist.world, &gp, &gw);
-    msm_dist_slice(n, gp, (uint32_t)ctx->dist.rank / gw, &first, &count);
+    msm_dist_split(ctx, curve, group, scalar_size, n, (uint32_t)world, &gp, &gw);
+    msm_dist_slice(n, gp, (uint32_t)my_rank / gw, &first, &count);
     const size_t bstride = (size_t)((flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group;
     const uint8_t* b = bases ? (const uint8_t*)bases + (size_t)first * bstride : nullptr;
     const uint8_t* s = scalars ? (const uint8_t*)scalars + (size_t)first * scalar_size : nullptr;
-    return dist_submit(ctx, curve, group, flags, b, s, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket);
+    return dist_submit(ctx, curve, group, flags, b, s, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket);
 }
 
 // This rank holds only ITS slice of the n_total points (msm_amd_dist_plan says which): bases_local / scalars_local are that slice.
 int msm_amd_multiexp_dist_local_async(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases_local, const void* scalars_local,
                                       uint32_t scalar_size, uint32_t n_local, uint32_t n_total, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
-    if (!ctx->dist.comm) {
+    int my_rank = 0, world = 0;
+    if (!dist_group(ctx, &my_rank, &world)) {
         msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
         return MSM_AMD_EINVAL;
     }
@@ -309,17 +320,17 @@ int msm_amd_multiexp_dist_local_async(msm_amd_ctx* ctx, int curve, int group, ui
         return MSM_AMD_EINVAL;
     }
     uint32_t gp, gw, first, count;
-    msm_dist_split(ctx, curve, group, scalar_size, n_total, (uint32_t)ctx->dist.world, &gp, &gw);
-    msm_dist_slice(n_total, gp, (uint32_t)ctx->dist.rank / gw, &first, &count);
+    msm_dist_split(ctx, curve, group, scalar_size, n_total, (uint32_t)world, &gp, &gw);
+    msm_dist_slice(n_total, gp, (uint32_t)my_rank / gw, &first, &count);
     if (n_local != count) {
         // the caller's buffers hold n_local points; reading `count` of them would run past their end (or drop points).  The split
         // depends on the context's options: plan and call must see the same ones.  Symmetric across ranks only if the caller's mistake
         // is -- so this rank still takes part in the exchange, with a failure mark.
         const std::string why = "multiexp_dist_local: n_local = " + std::to_string(n_local) + " but this rank's slice of " + std::to_string(n_total) +
                                 " points is " + std::to_string(count) + " (msm_amd_dist_plan; were options changed in between?)";
-        return dist_submit(ctx, curve, group, flags, nullptr, nullptr, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket, MSM_AMD_EINVAL, why);
+        return dist_submit(ctx, curve, group, flags, nullptr, nullptr, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket, MSM_AMD_EINVAL, why);
     }
-    return dist_submit(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, count, (uint32_t)ctx->dist.rank % gw, gw, ticket);
+    return dist_submit(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket);
 }
 
 // Waits for this rank's partial, takes part in the exchange of this call (one ncclAllGather of world x 304 bytes: a status word and
@@ -427,10 +438,13 @@ int msm_amd_multiexp_dist(msm_amd_ctx* ctx, int curve, int group, uint32_t flags
 int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* local_table, uint32_t flags, const void* scalars_local, uint32_t scalar_size,
                                          uint32_t n_local, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
-    if (!ctx->dist.comm) {
+    int my_rank = 0, world = 0;
+    if (!dist_group(ctx, &my_rank, &world)) {
         msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
         return MSM_AMD_EINVAL;
     }
+    (void)my_rank;
+    (void)world;
     uint32_t info[6];
     if (!local_table || msm_amd_bases_info(local_table, info, nullptr)) {
         msm_set_err(ctx, "multiexp_dist_prepared: no table");

@@ -130,7 +130,7 @@ struct msm_amd_ctx {
         std::map<uint64_t, Rec> recs;   // by dist ticket
         uint64_t next_id = 1, next_seq = 0, next_exchange = 0;
     } dist;
-    std::mutex dist_mu;
+    mutable std::mutex dist_mu;
     std::condition_variable dist_cv;   // next_exchange moved on
     std::vector<msm_amd_bases*> prepared_handles;   // handles this context has prepared and not released (guarded by mu): freed by msm_amd_destroy
     int even_windows = 1;              // option "even_windows": windows of c and c - 1 bits that tile the scalar exactly when c does not divide its width
@@ -185,7 +185,7 @@ inline void msm_dist_slice(uint32_t n, uint32_t gp, uint32_t p, uint32_t* first,
         hipError_t e_ = (call);                                                                                \
         if (e_ != hipSuccess) {                                                                                \
             msm_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e_));                             \
-            return MSM_AMD_EHIP;                                                                               \
+            return e_ == hipErrorOutOfMemory ? MSM_AMD_ENOMEM : MSM_AMD_EHIP;                                  \
         }                                                                                                      \
     } while (0)
 
