@@ -393,6 +393,48 @@ def test_prepared_bases_at_the_headline_size(eng, orc):
         pts.free()
 
 
+def test_prepared_bases_at_four_million_points(eng, orc):
+    """n = 2^22 + 4097 on a prepared table (13 windows over 2^19 buckets, 416+ index slices of the 13 x n table, spans of 200 000
+    entries cut into chunks): the same point as the general path on the same resident inputs -- one call at a time, two in flight,
+    and with either chunk size of the chunk-parallel fine sort -- and linear in the scalars: MSM(s) + MSM(t) = MSM(s + t) for
+    scalars whose sum does not leave 255 bits."""
+    import torch
+    import msm_amd
+    curve, group, n = "bls12381", 1, (1 << 22) + 4097
+    C = eng.curve(curve)
+    pts = C.gen_points(group, 0xF0E4, n)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4100)
+    s = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    t = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=gen)
+    s[:, 31] &= 0x3F
+    t[:, 31] &= 0x3F
+    # s + t as 256-bit little-endian integers (below 2^255): byte-wise with carry, on the GPU
+    acc = s.to(torch.int32) + t.to(torch.int32)
+    for k in range(31):
+        acc[:, k + 1] += acc[:, k] >> 8
+    st = (acc & 0xFF).to(torch.uint8).contiguous()
+    torch.cuda.synchronize()
+    pb = C.prepare_bases(group, pts, n)
+    try:
+        info = pb.info()
+        assert (info["c"], info["windows"]) == (20, 13)
+        full = C._multiexp(group, 0, pts, s, 32, n)
+        assert pb.multiexp(s) == full
+        for mode in (1, 2):
+            eng.set_option("chunk_mode", mode)
+            a, b = pb.multiexp_async(s), pb.multiexp_async(t)
+            rs, rt = a.wait(), b.wait()
+            assert rs == full, mode
+        eng.set_option("chunk_mode", 0)
+        assert msm_amd.combine(curve, group, rs + rt) == pb.multiexp(st)
+        assert pb.multiexp(st) == C._multiexp(group, 0, pts, st, 32, n)
+    finally:
+        eng.set_option("chunk_mode", 0)
+        pb.release()
+        pts.free()
+
+
 def test_index_slices_of_the_partition(eng, orc):
     """4-byte partition entries at every size: indices wider than the entry's index field put their high bits into the bin (S sub-bins
     per (window, coarse bin), csrc/sort_kernels.hpp SortGeom).  With 21-bit windows the field is 19 bits, with 20-bit ones 20: n = 700 001
