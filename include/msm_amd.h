@@ -88,7 +88,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * no faster, off by default), "even_windows" (default 1: when the window size does not divide the scalar width the windows are
  * c and c - 1 bits wide and tile it exactly -- no partly used top window; 0 = windows of c bits only, the round-2 layout),
  * "dist_gw" (window groups of a call of a multi-GPU group: 0 = planned per call, else a divisor of the world size); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
- * interleaved multiply-add chains, 2 one chain) and "acc_stream" (0 by launch size, 1 the slot's own stream, 2 the context's stream A). */
+ * interleaved multiply-add chains, 2 one chain), "acc_stream" (0 by launch size, 1 the slot's own stream, 2 the context's stream A),
+ * "tile_mode" (scalars per tile of the partition: 0 by size and load, 1 = 1024, 2 = 4096) and "chunk_mode" (entries per chunk of the
+ * chunk-parallel fine sort: 0 by size and load, 1 = 4096 on 256-lane workgroups, 2 = 8192 on 1024-lane ones). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 /* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
  * hardware queue (their kernels serialise).  HIP maps streams onto hardware queues in creation order across the whole process, and

@@ -475,8 +475,8 @@ int MsmCall<F>::sort() {
     sl->binhist_zero.set(sl->d_binhist);
     HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
     // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
-    // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four with 4-byte entries = 100 KB, two with
-    // 8-byte ones; the CU has 160 KB and hosts one 1024-lane workgroup)
+    // windows per phase: as many as the staged group fits in LDS (4096-item tiles: four windows of 4-byte entries = 100 KB; the CU has
+    // 160 KB and hosts one 1024-lane workgroup)
 #define MSM_TILE_SCATTER(NW, BL, E, GW)                                                                                              \
 do {                                                                                                                             \
     constexpr size_t lds_ = tile_scatter_lds<E>(4 * BL, GW, BL);                                                                  \
