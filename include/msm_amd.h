@@ -138,6 +138,11 @@ int msm_amd_release_bases(msm_amd_ctx *ctx, msm_amd_bases *bases);
 /* out6: [0] points, [1] scalar_bits, [2] c, [3] windows W, [4] signed windows (c bits; the other W - [4] are c - 1 bits, unsigned),
  * [5] buckets = 2^(c-1); *table_bytes (may be NULL): HBM held by the table */
 int msm_amd_bases_info(const msm_amd_bases *bases, uint32_t *out6, uint64_t *table_bytes);
+/* The same figures for a table that does not exist yet -- what msm_amd_prepare_bases would choose for n points and scalars below
+ * 2^scalar_bits (0 = the group order's width), window_bits = 0 or the forced window size -- so that a host can budget the HBM
+ * (W x n points: 12.5 x the bases at n = 2^20) before it prepares anything.  Needs neither a GPU nor a context. */
+int msm_amd_plan_prepared(int curve, int group, uint32_t n, uint32_t scalar_bits, uint32_t window_bits, uint32_t *out6,
+                          uint64_t *table_bytes);
 int msm_amd_multiexp_prepared(msm_amd_ctx *ctx, msm_amd_bases *bases, uint32_t flags, const void *scalars,
                               uint32_t scalar_size, uint32_t n, uint8_t *out);
 int msm_amd_multiexp_prepared_async(msm_amd_ctx *ctx, msm_amd_bases *bases, uint32_t flags, const void *scalars,
@@ -182,7 +187,8 @@ int msm_amd_dist_init(msm_amd_ctx *ctx, int rank, int world, const uint8_t *id12
 int msm_amd_dist_destroy(msm_amd_ctx *ctx);
 int msm_amd_dist_info(const msm_amd_ctx *ctx, int *rank, int *world); /* world = 0: not in a group */
 /* the split of a call of n points over a group of `world` ranks and the slice of the points rank `rank` = p * gw + w takes
- * (world = 0: this context's own group and rank) */
+ * (world = 0: this context's own group and rank).  With world != 0 ctx may be NULL (no GPU needed: a launcher can place the
+ * slices before any context exists); a context contributes its "dist_gw" option. */
 int msm_amd_dist_plan(const msm_amd_ctx *ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t rank,
                       uint32_t *gp, uint32_t *gw, uint32_t *first, uint32_t *count);
 int msm_amd_multiexp_dist(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases, const void *scalars,

@@ -106,7 +106,7 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
     *gp = 1;
     *gw = world ? world : 1;
     if (world <= 1) return;
-    if (ctx->dist_gw && world % ctx->dist_gw == 0) {
+    if (ctx && ctx->dist_gw && world % ctx->dist_gw == 0) {
         *gw = ctx->dist_gw;
         *gp = world / ctx->dist_gw;
         return;
@@ -235,8 +235,9 @@ int msm_amd_dist_info(const msm_amd_ctx* ctx, int* rank, int* world) {
 // gw window groups.  world = 0: this context's own group and rank.
 int msm_amd_dist_plan(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t rank, uint32_t* gp,
                       uint32_t* gw, uint32_t* first, uint32_t* count) {
-    if (!ctx || !gp || !gw || !first || !count) return MSM_AMD_EINVAL;
+    if (!gp || !gw || !first || !count) return MSM_AMD_EINVAL;
     if (world == 0) {
+        if (!ctx) return MSM_AMD_EINVAL;
         int r = 0, w = 0;
         if (!dist_group(ctx, &r, &w)) return MSM_AMD_EINVAL;
         world = (uint32_t)w;

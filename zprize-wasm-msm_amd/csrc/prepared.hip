@@ -206,6 +206,24 @@ int msm_amd_release_bases(msm_amd_ctx* ctx, msm_amd_bases* h) {
     return 0;
 }
 
+// The layout msm_amd_prepare_bases would choose, and what the table would take -- without building it (no GPU, no context).
+int msm_amd_plan_prepared(int curve, int group, uint32_t n, uint32_t scalar_bits, uint32_t window_bits, uint32_t* out6, uint64_t* table_bytes) {
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || n == 0 || scalar_bits > 512 || !out6) return MSM_AMD_EINVAL;
+    if (scalar_bits == 0) scalar_bits = curve == MSM_AMD_BLS12381 ? 255 : 254;
+    uint32_t c = 0, W = 0, ns = 0;
+    plan_prepared(n, scalar_bits, window_bits >= 3 ? window_bits : 0, &c, &W, &ns);
+    if (c == 0) return MSM_AMD_EINVAL;   // windows x points of the table would not stay below 2^31
+    out6[0] = n;
+    out6[1] = scalar_bits;
+    out6[2] = c;
+    out6[3] = W;
+    out6[4] = ns;
+    out6[5] = 1u << (c - 1);
+    const uint64_t affine = (uint64_t)2 * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (uint64_t)group;
+    if (table_bytes) *table_bytes = (uint64_t)W * (((uint64_t)n + 4095u) & ~4095ull) * affine;
+    return 0;
+}
+
 int msm_amd_bases_info(const msm_amd_bases* h, uint32_t* out6, uint64_t* table_bytes) {
     if (!h || !out6) return MSM_AMD_EINVAL;
     out6[0] = h->n;

@@ -51,6 +51,7 @@ static int (*p_set_option)(msm_amd_ctx *, const char *, uint32_t);
 static int (*p_prepare_bases)(msm_amd_ctx *, int, int, uint32_t, const void *, uint32_t, uint32_t, msm_amd_bases **);
 static int (*p_release_bases)(msm_amd_ctx *, msm_amd_bases *);
 static int (*p_bases_info)(const msm_amd_bases *, uint32_t *, uint64_t *);
+static int (*p_plan_prepared)(int, int, uint32_t, uint32_t, uint32_t, uint32_t *, uint64_t *);
 static int (*p_multiexp_prepared)(msm_amd_ctx *, msm_amd_bases *, uint32_t, const void *, uint32_t, uint32_t, uint8_t *);
 static int (*p_dist_id)(uint8_t *);
 static int (*p_dist_init)(msm_amd_ctx *, int, int, const uint8_t *);
@@ -110,6 +111,7 @@ static const char *load_engine(void) {
     SYM(p_prepare_bases, "msm_amd_prepare_bases")
     SYM(p_release_bases, "msm_amd_release_bases")
     SYM(p_bases_info, "msm_amd_bases_info")
+    SYM(p_plan_prepared, "msm_amd_plan_prepared")
     SYM(p_multiexp_prepared, "msm_amd_multiexp_prepared")
     SYM(p_dist_id, "msm_amd_dist_unique_id")
     SYM(p_dist_init, "msm_amd_dist_init")
@@ -594,7 +596,7 @@ static napi_value js_multiexp_resident(napi_env env, napi_callback_info info) {
 }
 
 /* ---- prepared bases (msm_amd_prepare_bases): prepareBases(ctx, curve, group, flags, bases: Uint8Array, n, scalarBits) -> handle ;
- *      multiexpPrepared(ctx, handle, scalars, scalarSize, n) -> Uint8Array ; multiexpPreparedAsync(...) -> Promise ; basesInfo(handle).
+ *      multiexpPrepared(ctx, handle, scalars, scalarSize, n) -> Uint8Array ; multiexpPreparedAsync(...) -> Promise ; basesInfo(handle) ; planPrepared(curve, group, n[, scalarBits[, windowBits]]).
  *      The window table of a prover's fixed points is built on the GPU once; every call then sorts all windows into one bucket set. */
 typedef struct {
     msm_amd_ctx *ctx;
@@ -648,9 +650,10 @@ static napi_value js_prepare_bases(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_external(env, b, prepared_finalize, NULL, &ext));
     return ext;
 }
+static napi_value bases_info_object(napi_env env, const uint32_t *v6, uint64_t tb);
 static napi_value js_bases_info(napi_env env, napi_callback_info info) {
     size_t argc = 1;
-    napi_value argv[1], obj, v;
+    napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     void *hb;
     if (argc < 1 || napi_get_value_external(env, argv[0], &hb) != napi_ok) {
@@ -660,7 +663,11 @@ static napi_value js_bases_info(napi_env env, napi_callback_info info) {
     uint32_t v6[6];
     uint64_t tb = 0;
     p_bases_info(((prepared_t *)hb)->h, v6, &tb);
+    return bases_info_object(env, v6, tb);
+}
+static napi_value bases_info_object(napi_env env, const uint32_t *v6, uint64_t tb) {
     static const char *names[6] = {"n", "scalarBits", "c", "windows", "signedWindows", "buckets"};
+    napi_value obj, v;
     NAPI_OK(napi_create_object(env, &obj));
     for (int i = 0; i < 6; ++i) {
         NAPI_OK(napi_create_uint32(env, v6[i], &v));
@@ -669,6 +676,31 @@ static napi_value js_bases_info(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_create_double(env, (double)tb, &v));
     NAPI_OK(napi_set_named_property(env, obj, "tableBytes", v));
     return obj;
+}
+/* planPrepared(curve, group, n[, scalarBits[, windowBits]]) -> what basesInfo would say of the table prepareBases would build (no GPU) */
+static napi_value js_plan_prepared(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    int curve, group;
+    uint32_t n, bits = 0, wb = 0;
+    const char *err = load_engine();
+    if (err) {
+        napi_throw_error(env, "MSM_AMD_NOLIB", err);
+        return NULL;
+    }
+    if (argc < 3 || get_i32(env, argv[0], &curve) || get_i32(env, argv[1], &group) || get_u32(env, argv[2], &n) ||
+        (argc >= 4 && get_u32(env, argv[3], &bits)) || (argc >= 5 && get_u32(env, argv[4], &wb))) {
+        napi_throw_type_error(env, NULL, "planPrepared(curve, group, n[, scalarBits[, windowBits]])");
+        return NULL;
+    }
+    uint32_t v6[6];
+    uint64_t tb = 0;
+    if (p_plan_prepared(curve, group, n, bits, wb, v6, &tb)) {
+        napi_throw_range_error(env, NULL, "planPrepared: bad curve / group / n / scalarBits, or windows x points of the table >= 2^31");
+        return NULL;
+    }
+    return bases_info_object(env, v6, tb);
 }
 typedef struct {
     prepared_t *b;
@@ -994,6 +1026,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"setOption", NULL, js_set_option, NULL, NULL, NULL, napi_enumerable, NULL},
         {"prepareBases", NULL, js_prepare_bases, NULL, NULL, NULL, napi_enumerable, NULL},
         {"basesInfo", NULL, js_bases_info, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"planPrepared", NULL, js_plan_prepared, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpPrepared", NULL, js_multiexp_prepared, NULL, NULL, NULL, napi_enumerable, NULL},
         {"multiexpPreparedAsync", NULL, js_multiexp_prepared_async, NULL, NULL, NULL, napi_enumerable, NULL},
         {"uploadBases", NULL, js_upload_bases, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -188,6 +188,8 @@ function curve(curveName, opts) {
                 const handle = native.prepareBases(ctx, C.id, g, jac ? FLAG_JACOBIAN : 0, buffBases, n, (opts2 && opts2.scalarBits) || 0);
                 return { handle, n, info: () => native.basesInfo(handle) };
             },
+            // what a table for n points would take, before building it: { c, windows, signedWindows, buckets, tableBytes, .. }
+            planPrepared: (n, opts2) => native.planPrepared(C.id, g, n, (opts2 && opts2.scalarBits) || 0, (opts2 && opts2.windowBits) || 0),
             multiExpPrepared: (prepared, buffScalars) => {
                 const scalarSize = Math.floor(buffScalars.byteLength / prepared.n);
                 return native.multiexpPreparedAsync(ctx, prepared.handle, buffScalars, scalarSize, prepared.n);

@@ -52,6 +52,13 @@ async function main() {
             const fsz = n8 * g, asz = 2 * fsz, jsz = 3 * fsz;
             const cid = msm.CURVES[curve].id;
             const zeroHex = Buffer.from(msm.native.combine(cid, g, new Uint8Array(0))).toString("hex");
+            // planning without a GPU: the headline table (13 windows of 20 / 19 bits over 2^19 buckets) and its size
+            {
+                const p = msm.native.planPrepared(cid, g, 1 << 20);
+                const want = curve === "bls12381" ? [255, 20, 13, 8] : [254, 20, 13, 7];
+                if ([p.scalarBits, p.c, p.windows, p.signedWindows].join() !== want.join() || p.tableBytes !== 13 * (1 << 20) * asz) throw new Error(`planPrepared ${curve} g${g}: ${JSON.stringify(p)}`);
+                checked++;
+            }
             // host-only helpers against the golden group-op outputs
             for (const rec of G.groupops) {
                 const got = Buffer.from(msm.native.normalize(cid, g, Buffer.from(rec.out_raw, "hex"))).toString("hex");
@@ -90,6 +97,8 @@ async function main() {
                 if (rec.n > 0 && rec.scalar_size * rec.n === scalars.length && rec.scalar_size <= 64) {
                     const pb = Gx.prepareBases(bases, { jacobian: !affine, scalarBits: 8 * rec.scalar_size });
                     if (pb.info().n !== rec.n) throw new Error("prepared bases: wrong point count");
+                    // the plan made without a GPU is the table that was built
+                    if (JSON.stringify(Gx.planPrepared(rec.n, { scalarBits: 8 * rec.scalar_size })) !== JSON.stringify(pb.info())) throw new Error("planPrepared differs from the table built");
                     const outP = await Gx.multiExpPrepared(pb, scalars);
                     if (Buffer.from(outP).toString("hex") !== canon(rec.out_norm, fsz, zeroHex)) throw new Error(`${curve} g${g} ${rec.id}: prepared-bases result differs`);
                 }

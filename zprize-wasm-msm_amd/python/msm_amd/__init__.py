@@ -93,6 +93,7 @@ def load_library(path=None):
     L.msm_amd_prepare_bases.argtypes = [vp, c.c_int, c.c_int, u32, vp, u32, u32, c.POINTER(vp)]
     L.msm_amd_release_bases.argtypes = [vp, vp]
     L.msm_amd_bases_info.argtypes = [vp, c.POINTER(u32), c.POINTER(c.c_uint64)]
+    L.msm_amd_plan_prepared.argtypes = [c.c_int, c.c_int, u32, u32, u32, c.POINTER(u32), c.POINTER(c.c_uint64)]
     L.msm_amd_multiexp_prepared.argtypes = [vp, vp, u32, vp, u32, u32, u8p]
     L.msm_amd_multiexp_prepared_async.argtypes = [vp, vp, u32, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_multiexp_dist_prepared.argtypes = [vp, vp, u32, vp, u32, u32, u8p]
@@ -614,6 +615,31 @@ def dist_unique_id():
     if L.msm_amd_dist_unique_id(out):
         raise MsmAmdError("msm_amd_dist_unique_id failed (RCCL not loadable?)")
     return out.raw
+
+
+# --- planning without a GPU or a context ---
+def plan_prepared(curve, group, n, scalar_bits=0, window_bits=0):
+    """msm_amd_plan_prepared: the layout and the size of the table Curve.prepare_bases would build (PreparedBases.info's fields)."""
+    L = load_library()
+    arr = (ctypes.c_uint32 * 6)()
+    tb = ctypes.c_uint64()
+    rc = L.msm_amd_plan_prepared(CURVES[curve], group, n, scalar_bits, window_bits, arr, ctypes.byref(tb))
+    if rc:
+        raise MsmAmdError(f"msm_amd_plan_prepared failed ({rc}): bad curve / group / n / scalar_bits, or windows x points >= 2^31", rc)
+    return {"n": arr[0], "scalar_bits": arr[1], "c": arr[2], "windows": arr[3], "signed_windows": arr[4], "buckets": arr[5], "table_bytes": tb.value}
+
+
+def plan_split(curve, group, scalar_size, n, world, rank):
+    """msm_amd_dist_plan without a context: {gp, gw, first, count} of rank `rank` of `world` for a call of n points (Engine.dist_plan
+    adds the engine's "dist_gw" option and its own group)."""
+    L = load_library()
+    if world < 1:
+        raise MsmAmdError("plan_split: world >= 1", EINVAL)
+    v = [ctypes.c_uint32() for _ in range(4)]
+    rc = L.msm_amd_dist_plan(None, CURVES[curve], group, scalar_size, n, world, rank, *[ctypes.byref(x) for x in v])
+    if rc:
+        raise MsmAmdError(f"msm_amd_dist_plan failed ({rc}): bad world / rank / scalar_size", rc)
+    return dict(zip(("gp", "gw", "first", "count"), (x.value for x in v)))
 
 
 # --- host-only helpers (no GPU, no context): the comparison functions the reference's tests use ---
