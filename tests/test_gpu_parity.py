@@ -207,12 +207,19 @@ def test_async_pipeline_two_in_flight(eng, orc):
         eng.set_option("slots", 2)
 
 
-def test_randomised_configurations(eng, orc):
+def _seeds(default):
+    """the committed seed, plus any in MSM_TEST_EXTRA_SEEDS (comma-separated; soak runs: tools/runs/r03_soak.sh)"""
+    extra = [int(x) for x in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if x.strip()]
+    return [default] + extra
+
+
+@pytest.mark.parametrize("seed", _seeds(20261003))
+def test_randomised_configurations(eng, orc, seed):
     """40 seeded random combinations of curve, n, scalar size, window bits, segment length, reduction fan-out and
     entry point (full / chunk / shard), each against the oracle."""
     import random
     import msm_amd
-    rnd = random.Random(20261003)
+    rnd = random.Random(seed)
     try:
         for it in range(40):
             curve = rnd.choice(["bls12381", "bn128"])

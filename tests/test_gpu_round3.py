@@ -6,6 +6,7 @@
   * window digits of exactly 2^(c-1) at c = 20 and 21 (the packed (bucket, rank) word of the coarse partition);
   * the sort's bin histogram growing between calls of one context (small-bin calls first, then a call with more bins)."""
 import ctypes
+import os
 import threading
 
 import pytest
@@ -558,14 +559,21 @@ def test_prepared_tables_inside_a_group(orc):
         eng.close()
 
 
-def test_randomised_round3_configurations(eng, orc):
+def _seeds(default):
+    """the committed seed, plus any in MSM_TEST_EXTRA_SEEDS (comma-separated; soak runs: tools/runs/r03_soak.sh)"""
+    extra = [int(x) for x in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if x.strip()]
+    return [default] + extra
+
+
+@pytest.mark.parametrize("seed", _seeds(20261004))
+def test_randomised_round3_configurations(eng, orc, seed):
     """60 seeded random combinations of what round 3 added: windows of even width on / off, any window size, scalar sizes whose bit
     count the window does or does not divide, prepared tables with a random declared width and forced window size, hybrid splits of
     2 .. 8 ranks summed on this GPU, the forms of the fine sort and of its chunks -- each against the oracle."""
     import random
     import msm_amd
     from msm_amd import dist as mdist
-    rnd = random.Random(20261004)
+    rnd = random.Random(seed)
     try:
         for it in range(60):
             curve = rnd.choice(["bls12381", "bn128"])
