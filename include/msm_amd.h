@@ -111,7 +111,10 @@ int msm_amd_multiexp_chunk(msm_amd_ctx *ctx, int curve, int group, uint32_t flag
  * writes the result.  Up to `slots` tickets (default 2, option "slots" 1..8) may be outstanding per context:
  * the engine overlaps the bucket reductions of older calls (one HIP stream per slot) with the sort and bucket
  * accumulation of the newest one (each slot has its own scratch buffers).  Inputs must stay valid and unchanged until the ticket has been waited for.
- * msm_amd_multiexp(...) == msm_amd_multiexp_async(...) + msm_amd_wait(...).                               */
+ * msm_amd_multiexp(...) == msm_amd_multiexp_async(...) + msm_amd_wait(...).
+ * When every slot is taken a submission waits as long as at least one of them is held by a SYNCHRONOUS call of another thread (that
+ * thread will free it); if all hold asynchronous tickets only the caller could free one, and the call fails with MSM_AMD_EINVAL
+ * ("wait for an older ticket first").  Calls may be issued from several threads on one context.            */
 int msm_amd_multiexp_async(msm_amd_ctx *ctx, int curve, int group, uint32_t flags, const void *bases,
                            const void *scalars, uint32_t scalar_size, uint32_t n, uint64_t *ticket);
 int msm_amd_wait(msm_amd_ctx *ctx, uint64_t ticket, uint8_t *out);

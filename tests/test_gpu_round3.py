@@ -559,6 +559,53 @@ def test_prepared_tables_inside_a_group(orc):
         eng.close()
 
 
+def test_one_prepared_table_shared_by_threads(eng, orc):
+    """Six threads call one prepared table and the plain entry point on the same context at once (the libuv workers behind unresolved
+    promises of a Node prover): every caller gets its own result; the table cannot be released while a call on it is in flight and
+    can right after the last one."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 4000
+    C = eng.curve(curve)
+    O = orc.Oracle(curve, group)
+    bases, _ = gu.random_case(curve, group, "gpu:prepthreads", n)
+    jobs = []
+    for t in range(5):
+        _, sc = gu.random_case(curve, group, f"gpu:prepthreads:{t}", n)
+        jobs.append((sc, O.normalize(O.multiexp_affine(bases, sc, 32, n))))
+    pb = C.prepare_bases(group, bases, n)
+    errors, refused = [], []
+
+    def worker(k):
+        try:
+            for rep in range(5):
+                sc, exp = jobs[(k + rep) % len(jobs)]
+                got = pb.multiexp(sc) if (k + rep) % 3 else C.g1m_multiexpAffine(bases, sc, 32, n)
+                if got != exp:
+                    errors.append((k, rep))
+                if k == 0 and rep == 2:
+                    t = pb.multiexp_async(sc)
+                    try:
+                        pb.release()
+                        errors.append("released with a call in flight")
+                    except msm_amd.MsmAmdError as e:
+                        refused.append(e.code)
+                    if t.wait() != exp:
+                        errors.append((k, "async"))
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    try:
+        assert not errors, errors
+        assert refused == [msm_amd.EINVAL]
+    finally:
+        pb.release()
+
+
 def _seeds(default):
     """the committed seed, plus any in MSM_TEST_EXTRA_SEEDS (comma-separated; soak runs: tools/runs/r03_soak.sh)"""
     extra = [int(x) for x in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if x.strip()]

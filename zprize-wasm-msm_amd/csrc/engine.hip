@@ -855,9 +855,10 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
                 break;
             }
         }
-        if (sl || !wait_for_slot) break;
-        // every slot is taken.  Slots held by synchronous calls of other threads will be collected by those threads: wait for one.
-        // If all of them hold asynchronous tickets, only the caller can free one -- waiting would never end.
+        if (sl) break;
+        // every slot is taken.  Slots held by synchronous calls of other threads will be collected by those threads: wait for one
+        // (asynchronous submissions too: round 3 -- a thread that pipelines its own calls beside other threads' synchronous ones
+        // used to be refused here).  If all of them hold asynchronous tickets, only the caller can free one -- waiting would never end.
         bool some_sync = false;
         for (uint32_t k = 0; k < ctx->nslots; ++k) some_sync |= ctx->slots[k].sync_owned;
         if (!some_sync) break;
