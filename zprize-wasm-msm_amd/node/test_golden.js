@@ -109,6 +109,27 @@ async function main() {
                 }
                 checked++;
             }
+            // many promises at once on one context (libuv workers calling into it side by side): plain, resident and prepared calls of
+            // the affine records with at least 16 points, each checked against its own golden result
+            {
+                const recs = G.msm.filter((r) => r.fn === "multiexpAffine" && r.n >= 16 && r.scalar_size <= 64).slice(0, 6);
+                const tables = [], jobs = [];
+                for (const rec of recs) {
+                    const [bases, scalars] = inputs(curve, G, pool, rec, asz);
+                    if (rec.scalar_size * rec.n !== scalars.length) continue;
+                    const want = canon(rec.out_norm, fsz, zeroHex);
+                    const pb = Gx.prepareBases(bases, { scalarBits: 8 * rec.scalar_size });
+                    tables.push(pb);
+                    for (let rep = 0; rep < 2; rep++) {
+                        jobs.push(Gx.multiExpAffine(bases, scalars).then((o) => [Buffer.from(o).toString("hex"), want, rec.id + " plain"]));
+                        jobs.push(Gx.multiExpPrepared(pb, scalars).then((o) => [Buffer.from(o).toString("hex"), want, rec.id + " prepared"]));
+                    }
+                }
+                for (const [got, want, what] of await Promise.all(jobs)) {
+                    if (got !== want) throw new Error(`${curve} g${g} ${what}: concurrent result differs`);
+                    checked++;
+                }
+            }
         }
     }
     // batch conversions through the export-shaped surface (tests/golden/golden_conv.json)
