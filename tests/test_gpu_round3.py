@@ -559,6 +559,34 @@ def test_prepared_tables_inside_a_group(orc):
         eng.close()
 
 
+def test_table_beyond_hbm_is_refused_with_enomem(orc):
+    """A table that does not fit the GPU's memory (2^27 BLS12-381 G2 points: 13 windows x 25.8 GB = 335 GB; the plan itself is valid,
+    1.74e9 table indices) fails in msm_amd_prepare_bases with MSM_AMD_ENOMEM -- the allocation is the first thing it does, the bases
+    are never read -- and leaves the context usable."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve("bls12381")
+        n = 1 << 27
+        plan = msm_amd.plan_prepared("bls12381", 2, n)
+        assert plan["table_bytes"] > 300e9 and plan["windows"] * n < 1 << 31
+        d = eng.alloc(n * 192)                       # (uninitialised: never read)
+        try:
+            with pytest.raises(msm_amd.MsmAmdError) as ei:
+                C.prepare_bases(2, d, n)
+            assert ei.value.code == msm_amd.ENOMEM, ei.value
+        finally:
+            d.free()
+        O = orc.Oracle("bls12381", 1)
+        bases, scalars = gu.random_case("bls12381", 1, "gpu:after-enomem", 300)
+        assert C.g1m_multiexpAffine(bases, scalars, 32, 300) == O.normalize(O.multiexp_affine(bases, scalars, 32, 300))
+        pb = C.prepare_bases(1, bases, 300)
+        assert pb.multiexp(scalars) == O.normalize(O.multiexp_affine(bases, scalars, 32, 300))
+        pb.release()
+    finally:
+        eng.close()
+
+
 def test_one_prepared_table_shared_by_threads(eng, orc):
     """Six threads call one prepared table and the plain entry point on the same context at once (the libuv workers behind unresolved
     promises of a Node prover): every caller gets its own result; the table cannot be released while a call on it is in flight and

@@ -344,8 +344,7 @@ static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, u
         HIPCHK(ctx, hipMalloc(&di, in_b));
         if (hipMalloc(&dout, out_b) != hipSuccess) {
             (void)hipFree(di);
-            msm_set_err(ctx, "hipMalloc failed");
-            return MSM_AMD_EHIP;
+            return msm_alloc_failed(ctx, "batch conversion");
         }
         (void)hipMemcpyAsync(di, in, in_b, hipMemcpyHostToDevice, st);
     }
@@ -429,8 +428,7 @@ static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* 
         HIPCHK(ctx, hipMalloc(&di, in_b));
         if (hipMalloc(&dout, n) != hipSuccess) {
             (void)hipFree(di);
-            msm_set_err(ctx, "hipMalloc failed");
-            return MSM_AMD_EHIP;
+            return msm_alloc_failed(ctx, "batch check");
         }
         (void)hipMemcpyAsync(di, points, in_b, hipMemcpyHostToDevice, st);
     }

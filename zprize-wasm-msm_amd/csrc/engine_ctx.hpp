@@ -185,9 +185,17 @@ inline void msm_dist_slice(uint32_t n, uint32_t gp, uint32_t p, uint32_t* first,
         hipError_t e_ = (call);                                                                                \
         if (e_ != hipSuccess) {                                                                                \
             msm_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e_));                             \
+            (void)hipGetLastError(); /* reported: the runtime's sticky copy must not fail the NEXT call's check */ \
             return e_ == hipErrorOutOfMemory ? MSM_AMD_ENOMEM : MSM_AMD_EHIP;                                  \
         }                                                                                                      \
     } while (0)
+
+// a failed device allocation outside HIPCHK: MSM_AMD_ENOMEM, the runtime's sticky error cleared
+inline int msm_alloc_failed(msm_amd_ctx* ctx, const char* what) {
+    (void)hipGetLastError();
+    msm_set_err(ctx, std::string(what) + ": out of device memory");
+    return MSM_AMD_ENOMEM;
+}
 
 inline int ensure(msm_amd_ctx* ctx, DevBuf& b, size_t bytes) {
     if (b.cap >= bytes && b.p) return 0;

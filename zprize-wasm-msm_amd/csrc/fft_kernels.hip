@@ -436,10 +436,14 @@ static int apply_key_t(msm_amd_ctx* ctx, uint32_t flags, const void* in, uint32_
     HIPCHK(ctx, hipMalloc(&dkey, 64));
     hipError_t e = hipSuccess;
     if (!dev) {
-        if (hipMalloc(&di, in_b) != hipSuccess || hipMalloc(&dout, out_b) != hipSuccess) {
-            msm_set_err(ctx, "hipMalloc failed");
-            return MSM_AMD_EHIP;
+        void *a = nullptr, *b = nullptr;
+        if (hipMalloc(&a, in_b) != hipSuccess || hipMalloc(&b, out_b) != hipSuccess) {
+            if (a) (void)hipFree(a);
+            (void)hipFree(dkey);
+            return msm_alloc_failed(ctx, "batchApplyKey");
         }
+        di = a;
+        dout = b;
         e = hipMemcpyAsync(di, in, in_b, hipMemcpyHostToDevice, st);
     }
     uint8_t key[64];
