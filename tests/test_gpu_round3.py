@@ -494,8 +494,8 @@ def test_context_destruction_frees_unreleased_tables(orc):
 
 
 def test_glv_schedule_right_after_skewed_calls(orc):
-    """The skew hint switches 16-bit windows to the even layout (1 signed + 16 unsigned windows: no carry window for scalars that use
-    all 256 bits).  The GLV schedule keeps its own eight signed 16-bit windows over the 128-bit halves whatever the hint says (a first
+    """Scalars that use all 256 bits switch 16-bit windows to the even layout over the declared width (1 signed + 16 unsigned windows: no
+    carry window; the hint that does it is set by entries in the overflow / carry window).  The GLV schedule keeps its own eight signed 16-bit windows over the 128-bit halves whatever the hint says (a first
     version left it with the even layout's signed-window count: wrong sums, caught by the order of the tests in a shared context)."""
     import msm_amd
     curve, group = "bls12381", 1
@@ -520,6 +520,48 @@ def test_glv_schedule_right_after_skewed_calls(orc):
         eng.set_window_bits(16)
         assert C.g1m_multiexpAffine(b2, s2, 32, m) == O.normalize(O.multiexp_affine(b2, s2, 32, m))
         assert eng.geometry()["windows"] == 17                          # hint still on: 1 signed + 16 unsigned windows
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("curve,order_bits", [("bn128", 254), ("bls12381", 255)])
+def test_windows_tile_the_group_orders_width_until_wider_scalars_show_up(orc, curve, order_bits):
+    """Where the window size does not divide 256 (14-bit windows here) the windows tile the EXPECTED width of 32-byte scalars -- the
+    group order's: 254 bits for BN254, 255 for BLS12-381 -- and one more window takes the bits above, empty for reduced scalars.
+    Scalars that do use those bits are still summed correctly (the reference reduces nothing: any 256-bit integer is a valid scalar);
+    the entries they put into the overflow window switch the following calls to windows that tile all 256 bits, and sixteen calls
+    later the engine tries the narrow layout again."""
+    import msm_amd
+    group, n = 1, 40000
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, reduced = gu.random_case(curve, group, f"gpu:expected:{curve}", n)           # scalars below r
+        exp = O.normalize(O.multiexp_affine(bases, reduced, 32, n))
+        c, W_narrow = 14, (order_bits + 14) // 14 + 1
+        W_wide = (256 + 14) // 14
+        for _ in range(2):
+            assert C.g1m_multiexpAffine(bases, reduced, 32, n) == exp
+            g = eng.geometry()
+            assert (g["c"], g["windows"]) == (c, W_narrow)
+            assert g["entries"] <= n * (W_narrow - 1)                                        # nothing in the overflow window
+        wide = b"".join(((0xC0 << 248) | int.from_bytes(reduced[32 * i:32 * i + 31], "little")).to_bytes(32, "little") for i in range(n))   # bits 254 and 255 set
+        expw = O.normalize(O.multiexp_affine(bases, wide, 32, n))
+        assert C.g1m_multiexpAffine(bases, wide, 32, n) == expw                              # narrow layout, overflow window in use
+        assert eng.geometry()["windows"] == W_narrow
+        assert C.g1m_multiexpAffine(bases, wide, 32, n) == expw                              # the hint: windows over all 256 bits
+        assert eng.geometry()["windows"] == W_wide
+        seen = []
+        for _ in range(18):                                                                  # reduced scalars again: the hint decays
+            assert C.g1m_multiexpAffine(bases, reduced, 32, n) == exp
+            seen.append(eng.geometry()["windows"])
+        assert seen[0] == W_wide and seen[-1] == W_narrow and seen == sorted(seen), seen
+        # a sharded call plans without the hint (every rank must choose the same layout from the arguments alone)
+        C.g1m_multiexpAffine(bases, wide, 32, n)
+        C.g1m_multiexpAffine(bases, wide, 32, n)
+        parts = b"".join(C.multiexp_shard(group, bases, wide, 32, n, r, 2) for r in range(2))
+        assert msm_amd.combine(curve, group, parts) == expw
     finally:
         eng.close()
 

@@ -61,6 +61,28 @@ struct KernelField<Fp<P, false>> {
     static constexpr bool chained_variant = true;   // bucket_g1_*_acc.hip
 };
 
+// bit length of the group order r: what scalars reduced mod r -- a prover's -- need of their 32 bytes
+template <class F>
+struct OrderBits {
+    static constexpr uint32_t value = 256;
+};
+template <bool U>
+struct OrderBits<Fp<Bls12381Fp, U>> {
+    static constexpr uint32_t value = 255;
+};
+template <>
+struct OrderBits<Fp2<Bls12381Fp>> {
+    static constexpr uint32_t value = 255;
+};
+template <bool U>
+struct OrderBits<Fp<Bn254Fp, U>> {
+    static constexpr uint32_t value = 254;
+};
+template <>
+struct OrderBits<Fp2<Bn254Fp>> {
+    static constexpr uint32_t value = 254;
+};
+
 }  // namespace msm
 
 // msm_amd_last_error: a per-thread copy taken under the error lock (the stored string may be rewritten by another thread)
@@ -271,14 +293,27 @@ int MsmCall<F>::plan() {
     // c - 1 bits wide and unsigned (no carry out of the top one), ns chosen so that they tile the nbits exactly -- both kinds fill their
     // 2^(c-1) buckets evenly (the layout of the prepared tables, Geom in engine_common.hpp).  Kept for nbits % c == 0 is the old
     // layout: its top window is full, and the carry-only window above it stays empty for scalars whose top bit is clear.
-    // It also replaces the old layout once recent calls have shown skew (skew_hint: buckets beyond the segment length): scalars that
-    // use their full declared width -- 256-bit values in 32 bytes -- carry out of the top c-bit window into the carry-only one, whose
-    // single bucket then holds n / 2 entries (4.7 instead of 2.8 ms per MSM at n = 2^20); 1 signed + 16 unsigned 15-bit windows have no
-    // carry window at all, for 6 % more additions.
-    const bool skewed = ctx->skew_hint.load() > 0 && a.nshards == 1 && !ctx->force_seg;
-    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || skewed)) {
-        g.W = (g.nbits + g.c) / g.c;
-        g.ns = g.nbits > g.W * (g.c - 1) ? g.nbits - g.W * (g.c - 1) : 0u;
+    // What is tiled is the EXPECTED width of the scalars, not the declared one: 32-byte scalars are expected below the group order
+    // (255 bits for BLS12-381, 254 for BN254 -- a prover's scalars are reduced), and the 1-2 bits above get one more window, the
+    // overflow window, which such scalars leave empty (no entries, no buckets touched, skipped by the reduction).  Tiling all 256
+    // bits instead leaves the top window of a 254-bit scalar a quarter used -- a quarter of its buckets, four times as dense: BN254 at
+    // n = 2^18 spent 0.95 ms in an accumulation of 0.45 ms' worth of additions, and queued over-long buckets for the tail kernels.
+    // The declared width IS tiled once recent calls have put entries into the overflow window (wide_hint; scalars that use all 256
+    // bits: with c-bit windows they also carry out of the top one into the carry-only window, whose single bucket then holds n / 2
+    // entries -- 4.7 instead of 2.8 ms per MSM at n = 2^20; 1 signed + 16 unsigned 15-bit windows have no such window, for 6 % more
+    // additions).  The hint decays over 16 calls without such entries being observable (the wide layout has no overflow window).
+    const bool wide = ctx->wide_hint.load() > 0 && a.nshards == 1 && !ctx->force_seg;
+    const uint32_t expected = (a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && !wide) ? OrderBits<F>::value : a.nbits;
+    sl->top_is_overflow = false;
+    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide)) {
+        g.W = (expected + g.c) / g.c;
+        g.ns = expected > g.W * (g.c - 1) ? expected - g.W * (g.c - 1) : 0u;
+        if (expected < g.nbits) {   // the overflow window: c - 1 bits from bit `expected` on cover the rest (nbits - expected <= 2 <= c - 1)
+            ++g.W;
+            sl->top_is_overflow = true;
+        }
+    } else if (!a.prepared && g.nbits % g.c == 0 && g.nbits > g.c) {
+        sl->top_is_overflow = true;   // c-bit windows that divide the width: the top one is the carry-only window
     }
     if (a.prepared) {   // the table's windows: ns signed of c bits, the rest unsigned of c - 1; all into ONE bucket set
         g.W = a.prepared->W;
@@ -305,6 +340,7 @@ int MsmCall<F>::plan() {
         g.nbits = 128;
         g.W = 8;
         g.ns = 8;   // eight signed 16-bit windows over the 128-bit halves, whatever layout the 256-bit scalar would have taken
+        sl->top_is_overflow = false;   // (127-bit magnitudes: the top window is an ordinary one)
     }
     g.Wl = 0;
     for (uint32_t w = 0; w < g.W; ++w)
@@ -743,6 +779,7 @@ int MsmCall<F>::reduce() {
     // the tail counters of the (last) accumulation: buckets that overflowed their segment tell the next calls that the input is skewed
     HIPCHK(ctx, hipMemcpyAsync(h_tail + 2, sl->d_tailctl.p, 16, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipMemcpyAsync(h_tail + 6, sl->d_flags.p, 4, hipMemcpyDeviceToHost, sb));   // scalars wider than a prepared table's windows
+    HIPCHK(ctx, hipMemcpyAsync(h_tail + 7, offset + (size_t)(g.Wl - 1) * g.half, 4, hipMemcpyDeviceToHost, sb));   // where the top owned window's entries start
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
     const uint32_t wgs_per_window = p0.wgs;
     sl->wgs_per_window = wgs_per_window;
@@ -780,6 +817,11 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         // calls of this context do (n = 2^20, 256-bit scalars: scatter stage 1.7 -> 0.3 ms from the second call on).
         if (h_tail[3] /* TailCtl::nbig */ > 0) ctx->skew_hint.store(16);
         else if (ctx->skew_hint.load() > 0) ctx->skew_hint.fetch_sub(1);
+        // entries in the overflow window (plan()): the scalars are wider than the group order -- the next calls tile the declared width
+        if (g.nshards == 1 && !g.merged) {
+            if (sl->top_is_overflow && entries > (uint64_t)h_tail[7]) ctx->wide_hint.store(16);
+            else if (ctx->wide_hint.load() > 0) ctx->wide_hint.fetch_sub(1);
+        }
         if (g.merged && h_tail[6]) {
             msm_set_err(ctx, "a scalar has bits beyond the scalar_bits these bases were prepared for (msm_amd_prepare_bases): "
                              "the table holds no window for them; prepare with a larger scalar_bits or use msm_amd_multiexp");

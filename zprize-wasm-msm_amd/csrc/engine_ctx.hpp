@@ -76,6 +76,7 @@ struct Slot {
     Geom g{};
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
+    bool top_is_overflow = false;   // the top owned window only holds what lies beyond the expected scalar width (plan(): empty for scalars below the group order)
     msm_amd_bases* prepared = nullptr;   // the call runs on a prepared table (released from in_flight when collected)
     DevBuf d_flags;                      // word 0: a scalar had bits beyond the windows of the prepared table
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
@@ -161,6 +162,7 @@ struct msm_amd_ctx {
     int glv_mode = 1;       // option "glv": 0 = never, 1 = where it pays (BLS12-381 G1, n <= 2^17), 2 = whenever it applies
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int reduce_pair = 0;    // option "reduce_pair" = 1: G1 bucket reduction with every point on a lane pair (measured: no gain)
+    std::atomic<int> wide_hint{0};   // > 0: recent calls had scalars beyond the group order's bit length (entries in the overflow window): windows tile the declared width
     std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
     float timings[8] = {};
