@@ -244,7 +244,8 @@ int MsmCall<F>::plan() {
     }
     if (small_est && !ctx->stream_s2) {
         // created on first use: the mere existence of a stream of another priority re-partitions the hardware queues and cost calls
-        // with a full-size accumulation ~5 % (measured); of another priority because only such streams never share a queue with S/A/B
+        // with a full-size accumulation ~5 % (measured in round 1; at the end of round 3 a context runs its full-size calls at the same 2.59 ms
+        // before and after small calls created this stream, profiles/r03_s2_state.txt); of another priority because only such streams never share a queue with S/A/B
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_s2, hipStreamNonBlocking, 1));
     }
     st = small_est ? ctx->stream_s2 : ctx->stream_s;
@@ -1241,6 +1242,7 @@ int msm_amd_debug_stream_sharing(msm_amd_ctx* ctx, uint8_t* out) {
 int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!ctx || !name) return MSM_AMD_EINVAL;
     if (!strcmp(name, "window_bits")) return msm_amd_set_window_bits(ctx, value);
+    std::lock_guard<std::mutex> lk(ctx->mu);   // options are read while a call is planned (submit holds the same lock)
     if (!strcmp(name, "segment")) { ctx->force_seg = value; return 0; }
     if (!strcmp(name, "reduce_l")) {
         // lanes per workgroup follow from L (rblock = min(256, max(64, buckets / L))) and the workgroup's LDS tree halves: a value that is
@@ -1285,6 +1287,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
 
 int msm_amd_set_window_bits(msm_amd_ctx* ctx, uint32_t c) {
     if (!ctx || c > (uint32_t)MAX_WINDOW_BITS) return MSM_AMD_EINVAL;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->force_c = c;
     return 0;
 }
