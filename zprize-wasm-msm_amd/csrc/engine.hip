@@ -306,7 +306,11 @@ int MsmCall<F>::plan() {
     const bool wide = ctx->wide_hint.load() > 0 && a.nshards == 1 && !ctx->force_seg;
     const uint32_t expected = (a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && !wide) ? OrderBits<F>::value : a.nbits;
     sl->top_is_overflow = false;
-    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide)) {
+    // (c-bit windows that divide the declared width keep the old layout while its top real window is at least half used by scalars of the
+    // expected width -- BLS12-381 at c = 16: 15 of 16 bits, signed: all 2^15 buckets; BN254 at c = 16 has 14 bits there, half the buckets
+    // twice as dense, and takes the even layout: 14 windows of 16 bits, 2 of 15)
+    const bool top_thin = g.nbits % g.c == 0 && expected < g.nbits && expected % g.c != 0 && expected % g.c < g.c - 1;
+    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide || top_thin)) {
         g.W = (expected + g.c) / g.c;
         g.ns = expected > g.W * (g.c - 1) ? expected - g.W * (g.c - 1) : 0u;
         if (expected < g.nbits) {   // the overflow window: c - 1 bits from bit `expected` on cover the rest (nbits - expected <= 2 <= c - 1)
