@@ -745,7 +745,7 @@ int MsmCall<F>::reduce() {
         sl->part_off[wl] = wl < w_split ? wl * p0.wgs : nparts0 + (wl - w_split) * p1.wgs;
         sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
     }
-    if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ)) return rc;
+    if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ + 64)) return rc;   // the partials, then the eight tail words (k_collect_tail)
     if (sl->h_partials_cap < (size_t)nparts * XSZ + 64) {
         if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
         sl->h_partials = nullptr;
@@ -753,7 +753,7 @@ int MsmCall<F>::reduce() {
         HIPCHK(ctx, hipHostMalloc(&sl->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
         sl->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
     }
-    uint8_t* partials = (uint8_t*)sl->d_partials.p;
+    uint8_t* partials = ctx->zero_copy ? (uint8_t*)sl->h_partials : (uint8_t*)sl->d_partials.p;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
     // G1, option "reduce_pair" = 1: the reduction runs every addition on a lane pair (8 product rounds instead of 14, 178 instead of
     // 256 registers).  Measured and left off (profiles/r02_reduce_lane_pair_tried.txt): the same time one call at a time, 4-5 % slower
@@ -776,15 +776,12 @@ int MsmCall<F>::reduce() {
         HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
     }
     HIPCHK(ctx, hipEventRecord(sl->ev[6], sb));
-    HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ, hipMemcpyDeviceToHost, sb));
-    // total number of scattered (pair, window) entries = last offset + last count (for the roofline accounting)
-    uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
-    HIPCHK(ctx, hipMemcpyAsync(h_tail, offset + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
-    HIPCHK(ctx, hipMemcpyAsync(h_tail + 1, count + (NB - 1), 4, hipMemcpyDeviceToHost, sb));
-    // the tail counters of the (last) accumulation: buckets that overflowed their segment tell the next calls that the input is skewed
-    HIPCHK(ctx, hipMemcpyAsync(h_tail + 2, sl->d_tailctl.p, 16, hipMemcpyDeviceToHost, sb));
-    HIPCHK(ctx, hipMemcpyAsync(h_tail + 6, sl->d_flags.p, 4, hipMemcpyDeviceToHost, sb));   // scalars wider than a prepared table's windows
-    HIPCHK(ctx, hipMemcpyAsync(h_tail + 7, offset + (size_t)(g.Wl - 1) * g.half, 4, hipMemcpyDeviceToHost, sb));   // where the top owned window's entries start
+    // one copy: the partials and, behind them, the tail words -- total number of scattered (pair, window) entries = last offset + last
+    // count (roofline accounting); the tail counters of the (last) accumulation: buckets that overflowed their segment tell the next
+    // calls that the input is skewed; scalars wider than a prepared table's windows; where the top owned window's entries start
+    k_collect_tail<<<1, 64, 0, sb>>>(offset, count, NB, (g.Wl - 1) * g.half, (const uint32_t*)sl->d_tailctl.p, (const uint32_t*)sl->d_flags.p,
+                                     reinterpret_cast<uint32_t*>(partials + (size_t)nparts * XSZ));
+    if (!ctx->zero_copy) HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ + 32, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
     const uint32_t wgs_per_window = p0.wgs;
     sl->wgs_per_window = wgs_per_window;
@@ -1265,6 +1262,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return 0; }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
     if (!strcmp(name, "chunk_mode")) { ctx->chunk_mode = value; return 0; }     // experiments: chunk-parallel fine sort, 1 = 4096-entry chunks / 256 lanes, 2 = 8192 / 1024, 0 = by what else is in flight

@@ -132,6 +132,23 @@ struct DigitSource {
     }
 };
 
+// The few words the host wants beside the window partials -- where the last bucket's entries end (= the number of entries), the tail
+// counters, the too-wide flag of a prepared table, where the top owned window's entries start -- gathered behind the partials so that
+// ONE copy brings everything back (six separate 4- to 16-byte copies cost ~40 us at the end of every call).
+__global__ void k_collect_tail(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count, uint32_t NB, uint32_t top_first,
+                               const uint32_t* __restrict__ tailctl, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        out[0] = offset[NB - 1];
+        out[1] = count[NB - 1];
+        out[2] = tailctl[0];
+        out[3] = tailctl[1];
+        out[4] = tailctl[2];
+        out[5] = tailctl[3];
+        out[6] = flags[0];
+        out[7] = offset[top_first];
+    }
+}
+
 // GLV schedule (BLS12-381 G1; SURVEY.md 8f rank 1, constants of build_glv.js:15-22): every scalar is split into two signed
 // 127-bit halves (glv::split_centered).  Virtual item 2i is (P_i, k1), item 2i+1 is (phi(P_i), k2) with phi(x, y) = (beta*x, y):
 // 2n items of 128 bits, 8 windows of 16 bits and no carry out of the last one.  The halves are written once (|k| in bits
