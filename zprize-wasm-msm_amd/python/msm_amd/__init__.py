@@ -239,6 +239,12 @@ class Engine:
     def dist_destroy(self):
         self._chk(self.L.msm_amd_dist_destroy(self.ctx))
 
+    def dist_info(self):
+        """(rank, world) of this engine's group; world = 0: not in a group"""
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self._chk(self.L.msm_amd_dist_info(self.ctx, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
     def dist_plan(self, curve, group, scalar_size, n, world=0, rank=0):
         """msm_amd_dist_plan: how a call of n points is split over a group of `world` ranks (0: this engine's own group and rank) --
         {gp, gw, first, count}: gp point slices x gw window groups; [first, first + count) is the slice of the points that rank
