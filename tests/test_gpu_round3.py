@@ -629,6 +629,55 @@ def test_table_beyond_hbm_is_refused_with_enomem(orc):
         eng.close()
 
 
+@pytest.mark.parametrize("curve,group,n,opts", [("bls12381", 1, 40000, {}), ("bn128", 1, 40000, {}), ("bls12381", 2, 6000, {"split2": 0}),
+                                                ("bls12381", 1, 9000, {"split2": 0, "window_bits": 16}), ("bn128", 2, 5000, {"split2": 0, "window_bits": 12})])
+def test_witness_like_scalars_and_their_hot_buckets(orc, curve, group, n, opts):
+    """Scalars as a prover's witness has them: 55 % ones, 10 % twos, 10 % zeros, 10 % below 2^16, the rest uniform -- ONE bucket of
+    window 0 holds more than half of all points.  Such a bucket is hot (csrc/engine_common.hpp): short segments, its own lane stops
+    early, its segment sums are folded by 32 workgroups and then one.  Against the oracle, against the same call with the hot path
+    switched off (option "hot" = 0: the ordinary segment path), on a prepared table, and with 64-bit values whose carry makes a hot
+    bucket ABOVE their top window."""
+    import msm_amd
+    import random
+    eng = msm_amd.Engine(0)
+    try:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, uniform = gu.random_case(curve, group, f"gpu:witness:{curve}:{group}:{n}", n)
+        rnd = random.Random(n)
+        sc = bytearray(uniform)
+        for i in range(n):
+            r = rnd.random()
+            if r < 0.55:
+                sc[32 * i:32 * i + 32] = (1).to_bytes(32, "little")
+            elif r < 0.65:
+                sc[32 * i:32 * i + 32] = (2).to_bytes(32, "little")
+            elif r < 0.75:
+                sc[32 * i:32 * i + 32] = bytes(32)
+            elif r < 0.85:
+                sc[32 * i + 2:32 * i + 32] = bytes(30)
+        sc = bytes(sc)
+        exp = O.normalize(O.multiexp_affine(bases, sc, 32, n))
+        f = C.g1m_multiexpAffine if group == 1 else C.g2m_multiexpAffine
+        for rep in range(3):                                    # (from the second call on the skew hint shapes the launch grids)
+            assert f(bases, sc, 32, n) == exp, rep
+        eng.set_option("hot", 0)
+        assert f(bases, sc, 32, n) == exp
+        eng.set_option("hot", 1)
+        pb = C.prepare_bases(group, bases, n)
+        try:
+            assert pb.multiexp(sc) == exp
+        finally:
+            pb.release()
+        m = n // 2
+        wide = b"".join(uniform[32 * i:32 * i + 8] + bytes(24) for i in range(m))     # 64-bit values: half of them carry out of window 3
+        assert f(bases, wide, 32, m) == O.normalize(O.multiexp_affine(bases, wide, 32, m))
+    finally:
+        eng.close()
+
+
 def test_one_prepared_table_shared_by_threads(eng, orc):
     """Six threads call one prepared table and the plain entry point on the same context at once (the libuv workers behind unresolved
     promises of a Node prover): every caller gets its own result; the table cannot be released while a call on it is in flight and

@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.join(ROOT, "zprize-wasm-msm_amd", "python"))
 import torch
 import msm_amd
 eng = msm_amd.Engine(0)
+if os.environ.get("HOT") is not None:
+    eng.set_option("hot", int(os.environ["HOT"]))
 C = eng.curve("bls12381")
 n = 1 << 20
 pts = C.gen_points(1, 0x5151, n)

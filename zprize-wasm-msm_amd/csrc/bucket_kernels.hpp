@@ -19,8 +19,40 @@ namespace msm {
 struct TailCtl {
     uint32_t nwork;   // segments queued
     uint32_t nbig;    // buckets that queued segments
-    uint32_t pad[2];
+    uint32_t nhot;    // of which hot (engine_common.hpp): their slots in the hot list
+    uint32_t pad;
 };
+MSM_D uint32_t* hot_list(TailCtl* ctl) { return reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(ctl) + HOT_LIST_OFFSET); }
+MSM_D const uint32_t* hot_list(const TailCtl* ctl) { return reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(ctl) + HOT_LIST_OFFSET); }
+MSM_D uint8_t* hot_part(const TailCtl* ctl) { return const_cast<uint8_t*>(reinterpret_cast<const uint8_t*>(ctl)) + HOT_PART_OFFSET; }
+// One lane queues what its bucket holds beyond `done` entries as segments of `st` entries: work items (bucket, first entry, length),
+// an entry in the big-bucket list (bucket, first segment, segments, hot slot + 1 or 0).
+// (reserve: the counters and the big-bucket entry, returns the first work item and their number; the items themselves are written by
+// queue_segments below or, in k_accumulate, by the whole wave)
+MSM_D uint32_t reserve_segments(TailCtl* __restrict__ ctl, uint4* __restrict__ biglist, uint32_t b, uint32_t cnt, uint32_t done, uint32_t st, bool may_be_hot,
+                                uint32_t* extra_out) {
+    const uint32_t extra = (cnt - done + st - 1u) / st;
+    const uint32_t base = atomicAdd(&ctl->nwork, extra);
+    const uint32_t bi = atomicAdd(&ctl->nbig, 1u);
+    uint32_t hot = 0;
+    if (may_be_hot && extra >= HOT_MIN_SEGS) {
+        const uint32_t h = atomicAdd(&ctl->nhot, 1u);
+        if (h < HOT_MAX) {
+            hot = h + 1u;
+            hot_list(ctl)[h] = bi;
+        }
+    }
+    biglist[bi] = make_uint4(b, base, extra, hot);
+    *extra_out = extra;
+    return base;
+}
+MSM_D uint4 segment_item(uint32_t b, uint32_t cnt, uint32_t done, uint32_t st, uint32_t j) { return make_uint4(b, done + j * st, min(st, cnt - done - j * st), 0u); }
+MSM_D void queue_segments(TailCtl* __restrict__ ctl, uint4* __restrict__ work, uint4* __restrict__ biglist, uint32_t b, uint32_t cnt, uint32_t done,
+                          uint32_t st, bool may_be_hot) {
+    uint32_t extra;
+    const uint32_t base = reserve_segments(ctl, biglist, b, cnt, done, st, may_be_hot, &extra);
+    for (uint32_t j = 0; j < extra; ++j) work[base + j] = segment_item(b, cnt, done, st, j);
+}
 
 // Buckets are held in the unsaturated representation of field_u.hpp / curve_u.hpp (BU<F>); bases arrive in
 // the packed image of the reference and are re-sliced on load (no arithmetic).
@@ -164,8 +196,8 @@ struct AccWaves {
 template <class F, int VARIANT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                      const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
-                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg,
-                                                     TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+                                                     const uint32_t* __restrict__ order, uint32_t nb, uint8_t* __restrict__ buckets, uint32_t seg, uint32_t seg_t,
+                                                     TailCtl* __restrict__ ctl, uint4* __restrict__ work, uint4* __restrict__ biglist) {
     constexpr uint32_t T = UKind<F>::type::LANES;   // lanes per bucket (2: Fp2 components on a lane pair)
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = gt / T, sub = gt % T;
@@ -179,7 +211,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
             cnt = count[b];
             off = offset[b];
         }
-        acc = accumulate_span_staged<F>(bases, xbeta, sorted, off, min(cnt, seg), tile);
+        // (a hot bucket's own lane stops after seg_t entries: the rest is cut into segments of that length for the tail kernels)
+        acc = accumulate_span_staged<F>(bases, xbeta, sorted, off, min(cnt, cnt > HOT_FACTOR * seg ? seg_t : seg), tile);
         if (r >= nb) return;
     } else
 #endif
@@ -188,15 +221,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AccWav
         b = order[r];
         cnt = count[b];
         off = offset[b];
-        acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, seg));
+        acc = accumulate_span<F>(bases, xbeta, sorted, off, min(cnt, cnt > HOT_FACTOR * seg ? seg_t : seg));
     }
     store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
-    if (cnt > seg && sub == 0) {
-        uint32_t extra = (cnt - 1) / seg;   // segments 1 .. extra
-        uint32_t base = atomicAdd(&ctl->nwork, extra);
-        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
-        biglist[bi] = make_uint4(b, base, extra, 0u);
-        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, (j + 1) * seg);
+    // what the bucket holds beyond its lane's share is queued for the tail kernels -- the work items of a hot bucket are tens of thousands:
+    // every lane of the wave that is still here writes its share of them
+    const uint32_t cap = cnt > HOT_FACTOR * seg ? seg_t : seg;
+    const bool need = cnt > cap && sub == 0;
+    uint32_t q_base = 0, q_extra = 0;
+    if (need) q_base = reserve_segments(ctl, biglist, b, cnt, cap, cap, cap != seg, &q_extra);
+    const uint64_t active = __ballot(1), needers = __ballot(need);
+    if (needers == 0) return;
+    const uint32_t lane = threadIdx.x & 63u, nact = (uint32_t)__popcll(active), myrank = (uint32_t)__popcll(active & ((1ull << lane) - 1ull));
+    for (uint64_t m = needers; m != 0; m &= m - 1) {
+        const int src = __ffsll((long long)m) - 1;
+        const uint32_t sb = (uint32_t)__shfl((int)b, src), scnt = (uint32_t)__shfl((int)cnt, src), scap = (uint32_t)__shfl((int)cap, src),
+                       sbase = (uint32_t)__shfl((int)q_base, src), sextra = (uint32_t)__shfl((int)q_extra, src);
+        for (uint32_t j = myrank; j < sextra; j += nact) work[sbase + j] = segment_item(sb, scnt, scap, scap, j);
     }
 }
 
@@ -237,7 +278,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWave
 template <class F>
 __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, uint32_t nb, uint32_t K,
                                                      const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
-                                                     TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+                                                     TailCtl* __restrict__ ctl, uint4* __restrict__ work, uint4* __restrict__ biglist) {
     constexpr uint32_t T = UKind<F>::type::LANES;
     const uint32_t gt = blockIdx.x * 64u + threadIdx.x, r = gt / T, sub = gt % T;
     if (r >= nb) return;   // (both lanes of a pair leave together)
@@ -245,13 +286,7 @@ __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__
     for (uint32_t s = 1; s < K; ++s) acc = BU<F>::add_ni(acc, load16<BU<F>>(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>)));
     const uint32_t b = order[r], cnt = count[b];
     store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
-    if (cnt > K * seg && sub == 0) {
-        const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
-        uint32_t base = atomicAdd(&ctl->nwork, extra);
-        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
-        biglist[bi] = make_uint4(b, base, extra, 0u);
-        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
-    }
+    if (cnt > K * seg && sub == 0) queue_segments(ctl, work, biglist, b, cnt, K * seg, seg, false);
 }
 
 // The join for many slices per bucket (K a power of two, 8..64): a 256-lane workgroup takes 256 / K buckets, lane (s, r) loads slice s
@@ -260,7 +295,7 @@ __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__
 template <class F>
 __global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, uint32_t nb, uint32_t K,
                                                           const uint8_t* __restrict__ slices, uint8_t* __restrict__ buckets, uint32_t seg,
-                                                          TailCtl* __restrict__ ctl, uint2* __restrict__ work, uint4* __restrict__ biglist) {
+                                                          TailCtl* __restrict__ ctl, uint4* __restrict__ work, uint4* __restrict__ biglist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     BU<F>* sh = reinterpret_cast<BU<F>*>(smem);   // [K][B][T]
     constexpr uint32_t T = UKind<F>::type::LANES;
@@ -276,27 +311,20 @@ __global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __rest
     if (s != 0 || !live) return;
     const uint32_t b = order[r], cnt = count[b];
     store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
-    if (cnt > K * seg && sub == 0) {
-        const uint32_t done = K * seg, extra = (cnt - done + seg - 1u) / seg;
-        uint32_t base = atomicAdd(&ctl->nwork, extra);
-        uint32_t bi = atomicAdd(&ctl->nbig, 1u);
-        biglist[bi] = make_uint4(b, base, extra, 0u);
-        for (uint32_t j = 0; j < extra; ++j) work[base + j] = make_uint2(b, done + j * seg);
-    }
+    if (cnt > K * seg && sub == 0) queue_segments(ctl, work, biglist, b, cnt, K * seg, seg, false);
 }
 
 template <class F>
 __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
-                                                          const TailCtl* __restrict__ ctl, const uint2* __restrict__ work, uint32_t seg,
+                                                          const TailCtl* __restrict__ ctl, const uint4* __restrict__ work,
                                                           uint8_t* __restrict__ seg_out) {
     constexpr uint32_t T = UKind<F>::type::LANES;
     const uint32_t nwork = ctl->nwork;
     const uint32_t gt = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t item = gt / T; item < nwork; item += gridDim.x * blockDim.x / T) {
-        uint2 w = work[item];
-        uint32_t len = min(seg, count[w.x] - w.y);
-        BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[w.x] + w.y, len);
+        const uint4 w = work[item];   // bucket, first entry, entries
+        BU<F> acc = accumulate_span<F>(bases, xbeta, sorted, offset[w.x] + w.y, w.z);
         store16(seg_out + ((size_t)item * T + gt % T) * sizeof(BU<F>), acc);
     }
 }
@@ -314,8 +342,8 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
     const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, nlt = blockDim.x / T;   // logical lane, component, logical lanes
     const uint32_t nbig = ctl->nbig;
     for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-        uint4 d = biglist[bi];   // bucket, first segment, number of segments
-        if (d.z <= TAIL_LANE_SEGS) continue;   // (uniform over the workgroup)
+        uint4 d = biglist[bi];   // bucket, first segment, number of segments, hot slot + 1
+        if (d.z <= TAIL_LANE_SEGS || d.w != 0) continue;   // (uniform over the workgroup; hot buckets: below)
         BU<F> loc = BU<F>::inf();
         for (uint32_t j = lt; j < d.z; j += nlt)
             loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
@@ -335,6 +363,29 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
         }
         __syncthreads();
     }
+    // hot buckets, first fold: workgroup item (slot, g) sums the segments g * nlt + lt, + HOT_GROUPS * nlt, ... of hot bucket `slot` and
+    // leaves ONE partial sum; k_combine_tail_lanes (the next launch) folds the HOT_GROUPS partials of every hot bucket
+    const uint32_t nhot = min(ctl->nhot, HOT_MAX);
+    uint8_t* part = hot_part(ctl);
+    for (uint32_t it = blockIdx.x; it < nhot * HOT_GROUPS; it += gridDim.x) {
+        const uint32_t slot = it / HOT_GROUPS, g = it % HOT_GROUPS;
+        const uint4 d = biglist[hot_list(ctl)[slot]];
+        BU<F> loc = BU<F>::inf();
+        for (uint32_t j = g * nlt + lt; j < d.z; j += HOT_GROUPS * nlt)
+            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
+        sh[threadIdx.x] = loc;
+        __syncthreads();
+        for (uint32_t s = nlt / 2; s > 0; s >>= 1) {
+            if (lt < s) {
+                BU<F> a = sh[threadIdx.x];
+                BU<F> bb = sh[threadIdx.x + s * T];
+                sh[threadIdx.x] = BU<F>::add_ni(a, bb);
+            }
+            __syncthreads();
+        }
+        if (lt == 0) store16(part + ((size_t)it * T + sub) * sizeof(BU<F>), sh[threadIdx.x]);
+        __syncthreads();
+    }
 }
 template <class F>
 __global__ void __launch_bounds__(64) k_combine_tail_lanes(const TailCtl* __restrict__ ctl, const uint4* __restrict__ biglist,
@@ -347,6 +398,30 @@ __global__ void __launch_bounds__(64) k_combine_tail_lanes(const TailCtl* __rest
         BU<F> acc = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
         for (uint32_t j = 0; j < d.z; ++j) acc = BU<F>::add_ni(acc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
         store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), acc);
+    }
+    // hot buckets, second fold: the HOT_GROUPS partial sums that k_combine_tail (the previous launch) left per hot bucket, by one wave
+    __shared__ __attribute__((aligned(16))) BU<F> shh[64];
+    constexpr uint32_t NLT = 64u / T;   // logical lanes of this 64-thread workgroup
+    static_assert(HOT_GROUPS <= NLT, "one logical lane per partial sum");
+    const uint32_t nhot = min(ctl->nhot, HOT_MAX), lt = threadIdx.x / T;
+    const uint8_t* part = hot_part(ctl);
+    for (uint32_t slot = blockIdx.x; slot < nhot; slot += gridDim.x) {
+        const uint4 d = biglist[hot_list(ctl)[slot]];
+        shh[threadIdx.x] = lt < HOT_GROUPS ? load16<BU<F>>(part + (((size_t)slot * HOT_GROUPS + lt) * T + sub) * sizeof(BU<F>)) : BU<F>::inf();
+        __syncthreads();
+        for (uint32_t s = NLT / 2; s > 0; s >>= 1) {
+            if (lt < s) {
+                BU<F> a = shh[threadIdx.x];
+                BU<F> bb = shh[threadIdx.x + s * T];
+                shh[threadIdx.x] = BU<F>::add_ni(a, bb);
+            }
+            __syncthreads();
+        }
+        if (lt == 0) {
+            BU<F> cur = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
+            store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), BU<F>::add_ni(cur, shh[threadIdx.x]));
+        }
+        __syncthreads();
     }
 }
 
@@ -497,7 +572,7 @@ void launch_bucket_reduce_pair(hipStream_t st, uint32_t nparts, uint32_t rblock,
 // the former is compiled with MSM_U_CHAINED_MADS (field_u.hpp), the latter -- kernels that run few waves -- without.
 template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist) {
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, uint32_t seg_t, void* ctl, void* work, void* biglist) {
     constexpr uint32_t T = UKind<F>::type::LANES;
 #if defined(MSM_U_CHAINED_MADS)
     static_assert(VARIANT == 1, "this translation unit builds the chained variant");
@@ -512,8 +587,8 @@ void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbet
 #if MSM_ACC_STAGED
     static_assert(MSM_ACC_BLOCK == 64, "the staged entry lists take single-wave workgroups");
 #endif
-    k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK), MSM_ACC_BLOCK, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, (TailCtl*)ctl,
-                                                                                (uint2*)work, (uint4*)biglist);
+    k_accumulate<F, VARIANT><<<(uint32_t)(((uint64_t)nb * T + MSM_ACC_BLOCK - 1) / MSM_ACC_BLOCK), MSM_ACC_BLOCK, 0, st>>>(bases, xbeta, sorted, offset, count, order, nb, buckets, seg, seg_t, (TailCtl*)ctl,
+                                                                                (uint4*)work, (uint4*)biglist);
 }
 template <class F, int VARIANT>
 void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
@@ -532,11 +607,11 @@ void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const
     constexpr uint32_t T = UKind<F>::type::LANES;
     if (k >= 8 && (k & (k - 1)) == 0 && k * T <= 256) {
         const uint32_t B = 256u / (k * T);
-        k_join_slices_tree<F><<<(nb + B - 1u) / B, 256, (size_t)256 * sizeof(BU<F>), st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work,
+        k_join_slices_tree<F><<<(nb + B - 1u) / B, 256, (size_t)256 * sizeof(BU<F>), st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint4*)work,
                                                                                       (uint4*)biglist);
         return;
     }
-    k_join_slices<F><<<(uint32_t)(((uint64_t)nb * T + 63u) / 64u), 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint2*)work, (uint4*)biglist);
+    k_join_slices<F><<<(uint32_t)(((uint64_t)nb * T + 63u) / 64u), 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint4*)work, (uint4*)biglist);
 }
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
@@ -546,7 +621,8 @@ void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t*
     // segment) the grids are small: a launch ends when its LAST workgroup has found the queue empty, and on a chip whose SIMDs are full
     // of other calls' accumulation waves every workgroup waits for register room -- the empty 1024-workgroup launch took 55 us there.
     const uint32_t g_acc = tail_expected ? 1024u : 16u, g_blk = tail_expected ? 64u : 4u, g_lane = tail_expected ? 512u : 8u;
-    k_accumulate_tail<F><<<g_acc, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint2*)work, seg, seg_out);
+    k_accumulate_tail<F><<<g_acc, 256, 0, st>>>(bases, xbeta, sorted, offset, count, (const TailCtl*)ctl, (const uint4*)work, seg_out);
+    (void)seg;
     constexpr uint32_t T = UKind<F>::type::LANES;   // tail_block and rblock count LOGICAL lanes (points); a point takes T threads
     k_combine_tail<F><<<g_blk, tail_block * T, (size_t)tail_block * T * sizeof(BU<F>), st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
     k_combine_tail_lanes<F><<<g_lane, 64, 0, st>>>((const TailCtl*)ctl, (const uint4*)biglist, seg_out, buckets);
@@ -573,7 +649,7 @@ uint32_t lanes_per_point() {
 
 #define MSM_INSTANTIATE_ACCUMULATE(F, VARIANT)                                                                                               \
     template void launch_accumulate<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
-                                       uint32_t, uint8_t*, uint32_t, void*, void*, void*);
+                                       uint32_t, uint8_t*, uint32_t, uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_SLICES(F, VARIANT)                                                                                                   \
     template void launch_accumulate_slices<F, VARIANT>(hipStream_t, uint32_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
                                                        const uint32_t*, uint32_t, uint8_t*, uint32_t);

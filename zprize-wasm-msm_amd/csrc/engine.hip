@@ -26,7 +26,7 @@ namespace msm {
 // launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
 template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
-                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist);
+                       const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, uint32_t seg_t, void* ctl, void* work, void* biglist);
 template <class F, int VARIANT>
 void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                               const uint32_t* count, const uint32_t* order, uint32_t nb, uint8_t* slices, uint32_t seg);
@@ -657,9 +657,14 @@ int MsmCall<F>::accumulate() {
         seg = std::max(std::max(seg, bound(2ull * mean)), std::min(seg_hi, cap));
     }
     const uint32_t seg_min = (seg + std::max(k_first, k_second) - 1) / std::max(k_first, k_second);
-    const size_t max_segs = (size_t)g.Wl * nve / seg_min + 1;
-    if (int rc = ensure(ctx, sl->d_tailctl, sizeof(uint32_t) * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_work, max_segs * 8)) return rc;
+    // Hot buckets (engine_common.hpp: more than HOT_FACTOR x seg entries -- a witness full of ones puts 0.3 n entries into ONE bucket) are
+    // cut into segments of seg_t entries instead of seg: as short as the segment lists allow (2^19 segments at most: 16 entries at small n,
+    // 34 at n = 2^20, `seg` itself from n ~ 2^22 on, where the ordinary lanes run that long anyway).
+    const uint64_t all_entries = (uint64_t)g.Wl * nve;
+    const uint32_t seg_t = ctx->no_hot ? seg : (uint32_t)std::min<uint64_t>(seg, std::max<uint64_t>(16, (all_entries + (1u << 19) - 1) >> 19));
+    const size_t max_segs = (size_t)(all_entries / seg_min + all_entries / seg_t + 2);
+    if (int rc = ensure(ctx, sl->d_tailctl, HOT_PART_OFFSET + (size_t)HOT_MAX * HOT_GROUPS * BSZ)) return rc;   // counters, hot list, hot partial sums
+    if (int rc = ensure(ctx, sl->d_work, max_segs * 16)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
     if (int rc = ensure(ctx, sl->d_segout, max_segs * BSZ)) return rc;
     if (k_first > 1 || k_second > 1)
@@ -680,15 +685,15 @@ int MsmCall<F>::accumulate() {
                 else launch_accumulate_slices<FK, 0>(st, k, d_bases, d_xbeta, sorted, offset, count, ord, nbk, slices, seg_lane);
                 launch_join_slices<FK>(st, k, count, ord, nbk, slices, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
             } else if (chained)
-                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+                launch_accumulate<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, seg_t, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
             else
-                launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+                launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, seg_t, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         } else if (k > 1) {
             uint8_t* slices = (uint8_t*)sl->d_slices.p;
             launch_accumulate_slices<FK, 0>(st, k, d_bases, d_xbeta, sorted, offset, count, ord, nbk, slices, seg_lane);
             launch_join_slices<FK>(st, k, count, ord, nbk, slices, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         } else {
-            launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+            launch_accumulate<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, nbk, buckets, seg, seg_t, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
         }
         launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg_lane, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
                                    (uint8_t*)sl->d_segout.p, tail_block, tail_expected);
@@ -817,6 +822,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         // Skewed input (buckets beyond the segment length: scalars wider than the group order, a hot bucket, adversarial data) usually
         // means long spans in the fine sort as well, which the sort only cuts into parallel chunks when it expects them: the next
         // calls of this context do (n = 2^20, 256-bit scalars: scatter stage 1.7 -> 0.3 ms from the second call on).
+        if (getenv("MSM_AMD_DEBUG_TAIL")) fprintf(stderr, "msm_amd tail: %u segments, %u big buckets, %u hot\n", h_tail[2], h_tail[3], h_tail[4]);
         if (h_tail[3] /* TailCtl::nbig */ > 0) ctx->skew_hint.store(16);
         else if (ctx->skew_hint.load() > 0) ctx->skew_hint.fetch_sub(1);
         // entries in the overflow window (plan()): the scalars are wider than the group order -- the next calls tile the declared width
@@ -1262,6 +1268,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "hot")) { ctx->no_hot = value == 0; return 0; }   // 0 = hot buckets take the ordinary segment path (before / after measurements)
     if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return 0; }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)

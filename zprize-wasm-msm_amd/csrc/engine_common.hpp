@@ -37,6 +37,15 @@ MSM_D void store16(void* p, const T& t) {
     for (int k = 0; k < (int)(sizeof(T) / 16); ++k) s[k] = make_uint4(d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]);
 }
 
+// Hot buckets (bucket_kernels.hpp): a bucket that holds more than HOT_FACTOR x the segment length -- digit 1 of window 0 of a witness
+// full of ones, the carry out of the top used window of 64-bit values: 0.3 n .. 0.5 n entries -- is cut into SHORT segments (`seg_t`
+// entries, chosen by the engine so that the segment lists stay bounded), its main lane adds only that many itself, and its segment sums
+// are folded by HOT_GROUPS workgroups (then one): three short dependent chains instead of one of hundreds of additions.  Up to HOT_MAX
+// such buckets per accumulation launch; further ones take the ordinary path (correct, slower).  Behind the tail counters in `ctl`:
+// the list of hot buckets' entries in the big-bucket list, then the HOT_MAX x HOT_GROUPS partial sums.
+constexpr uint32_t HOT_FACTOR = 32, HOT_GROUPS = 32, HOT_MAX = 1024, HOT_MIN_SEGS = 256;
+constexpr size_t HOT_LIST_OFFSET = 16, HOT_PART_OFFSET = HOT_LIST_OFFSET + (size_t)HOT_MAX * 4;   // bytes from `ctl`
+
 constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 8 coarse + 12 fine bits of bucket index (the sort's two levels, sort_kernels.hpp)
 
 // Window geometry shared by host and kernels.

@@ -154,6 +154,7 @@ struct msm_amd_ctx {
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
+    int no_hot = 0;         // option "hot" = 0: no short segments / grouped fold for hot buckets
     int zero_copy = 1;      // option "zero_copy" (default 1): the reduction writes its partials and the tail words straight into the pinned host buffer -- no copy back (15 us of every call); 0 = device buffer + one copy
     int no_split2 = 0;      // option "split2" = 0: one lane per bucket always (switches k_accumulate_slices off)
     uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0, chunk_mode = 0;
