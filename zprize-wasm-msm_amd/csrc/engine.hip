@@ -658,10 +658,10 @@ int MsmCall<F>::accumulate() {
     }
     const uint32_t seg_min = (seg + std::max(k_first, k_second) - 1) / std::max(k_first, k_second);
     // Hot buckets (engine_common.hpp: more than HOT_FACTOR x seg entries -- a witness full of ones puts 0.3 n entries into ONE bucket) are
-    // cut into segments of seg_t entries instead of seg: as short as the segment lists allow (2^19 segments at most: 16 entries at small n,
-    // 34 at n = 2^20, `seg` itself from n ~ 2^22 on, where the ordinary lanes run that long anyway).
+    // cut into segments of seg_t entries instead of seg: as short as the segment lists allow (2^20 segments at most: 16 entries up to n = 2^19,
+    // 17 at n = 2^20, `seg` itself from n ~ 2^23 on, where the ordinary lanes run that long anyway).
     const uint64_t all_entries = (uint64_t)g.Wl * nve;
-    const uint32_t seg_t = ctx->no_hot ? seg : (uint32_t)std::min<uint64_t>(seg, std::max<uint64_t>(16, (all_entries + (1u << 19) - 1) >> 19));
+    const uint32_t seg_t = ctx->no_hot ? seg : (uint32_t)std::min<uint64_t>(seg, std::max<uint64_t>(16, (all_entries + (1u << 20) - 1) >> 20));
     const size_t max_segs = (size_t)(all_entries / seg_min + all_entries / seg_t + 2);
     if (int rc = ensure(ctx, sl->d_tailctl, HOT_PART_OFFSET + (size_t)HOT_MAX * HOT_GROUPS * BSZ)) return rc;   // counters, hot list, hot partial sums
     if (int rc = ensure(ctx, sl->d_work, max_segs * 16)) return rc;
