@@ -89,6 +89,9 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  * c and c - 1 bits wide and tile the width that 32-byte scalars are EXPECTED to use -- the group order's: 255 / 254 bits -- exactly, with one
  * more window for the bits above, which reduced scalars leave empty; scalars that do use those bits give the same result as ever and switch the
  * following calls of the context to windows over all 256 bits; 0 = windows of c bits only, the round-2 layout),
+ * "hot" (default 1: a bucket that holds more than 32 x the segment length -- a witness full of ones puts most points into one bucket -- is cut into
+ * short segments and its segment sums are folded by 32 workgroups; 0 = the ordinary segment path, for before / after measurements; with the
+ * environment variable MSM_AMD_DEBUG_TAIL set every collected call prints its segment / long-bucket / hot-bucket counts to stderr),
  * "zero_copy" (default 1: the window partials are written by the reduction kernel straight into pinned host memory; 0 = into a device
  * buffer that is copied back),
  * "dist_gw" (window groups of a call of a multi-GPU group: 0 = planned per call, else a divisor of the world size); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
