@@ -678,6 +678,33 @@ def test_witness_like_scalars_and_their_hot_buckets(orc, curve, group, n, opts):
         eng.close()
 
 
+@pytest.mark.parametrize("curve,group", [("bls12381", 1), ("bn128", 1), ("bn128", 2)])
+def test_a_bucket_with_most_of_the_points_folded_by_many_workgroups(orc, curve, group):
+    """n = 100 000 with 80 % ones: the bucket of digit 1 holds 80 000 entries -- 5 000 segments of 16, enough (HOT_MIN_SEGS = 4096,
+    csrc/engine_common.hpp) for the grouped fold: 32 workgroups sum a stripe of the segment results each, one wave sums the 32 partial
+    sums.  Against the oracle, against the ordinary path (option "hot" = 0), one call and two in flight."""
+    import msm_amd
+    import random
+    n = 100000
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, uniform = gu.random_case(curve, group, f"gpu:hotfold:{curve}:{group}", n)
+        rnd = random.Random(7)
+        one = (1).to_bytes(32, "little")
+        sc = b"".join(one if rnd.random() < 0.8 else uniform[32 * i:32 * i + 32] for i in range(n))
+        exp = O.normalize(O.multiexp_affine(bases, sc, 32, n))
+        for rep in range(3):
+            assert C._multiexp(group, 0, bases, sc, 32, n) == exp, rep
+        t1, t2 = C.multiexp_async(group, bases, sc, 32, n), C.multiexp_async(group, bases, sc, 32, n)
+        assert t1.wait() == exp and t2.wait() == exp
+        eng.set_option("hot", 0)
+        assert C._multiexp(group, 0, bases, sc, 32, n) == exp
+    finally:
+        eng.close()
+
+
 def test_one_prepared_table_shared_by_threads(eng, orc):
     """Six threads call one prepared table and the plain entry point on the same context at once (the libuv workers behind unresolved
     promises of a Node prover): every caller gets its own result; the table cannot be released while a call on it is in flight and

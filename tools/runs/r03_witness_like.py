@@ -28,7 +28,7 @@ def mix(pz, p1, psmall, small_bytes=2, p64=0.0):
     s[mid, 8:] = 0
     return s.contiguous()
 cases = [("uniform below 2^254", uni), ("50 % zero, 50 % uniform", mix(0.5, 0, 0)), ("30 % zero, 30 % one, 20 % below 2^16, 20 % uniform", mix(0.3, 0.3, 0.2)),
-         ("10 % zero, 60 % below 2^16, 30 % uniform", mix(0.1, 0.0, 0.6)), ("all below 2^64", mix(0, 0, 0, p64=1.0)), ("90 % one, 10 % uniform", mix(0.0, 0.9, 0.0))]
+         ("10 % zero, 60 % below 2^16, 30 % uniform", mix(0.1, 0.0, 0.6)), ("all below 2^64", mix(0, 0, 0, p64=1.0)), ("all below 2^128 (batching challenges)", uni.clone().index_fill_(1, torch.arange(16, 32, device="cuda"), 0).contiguous()), ("90 % one, 10 % uniform", mix(0.0, 0.9, 0.0))]
 torch.cuda.synchronize()
 def timed(fn, steps=40, depth=2):
     fl = []

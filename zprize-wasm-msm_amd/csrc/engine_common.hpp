@@ -43,7 +43,7 @@ MSM_D void store16(void* p, const T& t) {
 // are folded by HOT_GROUPS workgroups (then one): three short dependent chains instead of one of hundreds of additions.  Up to HOT_MAX
 // such buckets per accumulation launch; further ones take the ordinary path (correct, slower).  Behind the tail counters in `ctl`:
 // the list of hot buckets' entries in the big-bucket list, then the HOT_MAX x HOT_GROUPS partial sums.
-constexpr uint32_t HOT_FACTOR = 32, HOT_GROUPS = 32, HOT_MAX = 1024, HOT_MIN_SEGS = 256;
+constexpr uint32_t HOT_FACTOR = 32, HOT_GROUPS = 32, HOT_MAX = 1024, HOT_MIN_SEGS = 4096;   // (fewer segments than that: one workgroup folds them -- 32 trees over a few hundred values cost more than they save)
 constexpr size_t HOT_LIST_OFFSET = 16, HOT_PART_OFFSET = HOT_LIST_OFFSET + (size_t)HOT_MAX * 4;   // bytes from `ctl`
 
 constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 8 coarse + 12 fine bits of bucket index (the sort's two levels, sort_kernels.hpp)
