@@ -43,6 +43,10 @@ def test_headline_layout_and_table_size():
     assert (p["scalar_bits"], p["c"], p["windows"], p["signed_windows"], p["buckets"]) == (255, 20, 13, 8, 1 << 19)
     assert p["table_bytes"] == 13 * (1 << 20) * 96
     assert msm_amd.plan_prepared("bn128", 1, 1 << 20)["scalar_bits"] == 254
+    # a width that 20-bit windows overshoot (7 x 19 = 133 > 128: a thin top window) takes the nearest size that tiles it exactly
+    p = msm_amd.plan_prepared("bls12381", 1, 1 << 20, 128)
+    assert (p["c"], p["windows"], p["signed_windows"]) == (19, 7, 2) and 2 * 19 + 5 * 18 == 128
+    assert msm_amd.plan_prepared("bls12381", 1, 1 << 20, 128, 20)["c"] == 20          # a forced size is a forced size
 
 
 @pytest.mark.parametrize("curve,group", list(AFFINE))

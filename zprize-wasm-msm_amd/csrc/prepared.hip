@@ -73,6 +73,18 @@ static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t
         while ((2ull << lg) <= n) ++lg;   // floor(log2 n)
         want = n >= (1u << 19) ? 20u : lg;
     }
+    if (want && !forced_c && want > 4) {
+        // the windows should tile the scalar width EXACTLY (W (c - 1) <= bits: then ns >= 0 signed windows make up the difference); a
+        // width the wanted size overshoots -- 128-bit challenges at c = 20: 7 x 19 = 133 bits, the top window 14 of 19 bits wide, its
+        // 2^14 buckets 32 times as dense as the rest -- takes the nearest size that does: 19 (7 windows, 2 of them signed)
+        for (uint32_t c : {want, want - 1, want + 1, want - 2}) {
+            uint32_t W, ns;
+            if (c >= 3 && c <= (uint32_t)MAX_WINDOW_BITS && layout(c, &W, &ns) && (uint64_t)W * (c - 1) <= bits) {
+                want = c;
+                break;
+            }
+        }
+    }
     if (want) {
         // (a table too large for 31-bit entry indices at the wanted size takes the nearest wider window that fits)
         for (uint32_t c = std::min<uint32_t>(want, MAX_WINDOW_BITS); c <= (uint32_t)MAX_WINDOW_BITS; ++c)
