@@ -58,20 +58,47 @@ def uniform_scalars_mod_r(n, seed, r=R_BLS):
     return out.view(np.uint8).reshape(n, 32)
 
 
+def count_gpus_sysfs():
+    """GPUs of this node as the kernel driver lists them: the KFD topology nodes with SIMDs (CPU nodes have simd_count 0).  Reads sysfs
+    only -- no HIP, no torch: the parent of `--gpus N` must not initialise a GPU runtime before it starts its ranks.  None when the
+    topology is not readable (no amdgpu driver in this container, a different kernel layout): the caller then skips its pre-check."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    count = 0
+    seen = False
+    for nd in nodes:
+        try:
+            with open(os.path.join(base, nd, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+        except OSError:
+            continue
+        seen = True
+        if int(props.get("simd_count", "0")) > 0:
+            count += 1
+    return count if seen else None
+
+
 def launch_ranks(n):
     """Parent of a `python bench.py --gpus N` run: N child ranks (one process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
     their environment, exactly what torch.distributed.run would set), rank 0's stdout forwarded, exit code = the worst child's.
-    The parent itself never touches the GPU (torch.cuda.device_count() only reads the driver's device list on this image)."""
+    The parent never imports torch, the engine or anything else that could start a GPU runtime: the GPUs are counted from sysfs
+    (MSM_BENCH_FAKE_GPU_COUNT overrides the count: launcher tests), and where sysfs says nothing the ranks find out themselves --
+    a rank whose LOCAL_RANK has no GPU fails, and the first failing child ends the job."""
     import socket
     import subprocess
     backend = os.environ.get("MSM_BENCH_BACKEND", "nccl")
     if backend == "nccl" and os.environ.get("MSM_BENCH_LAUNCH_ONLY", "") != "1":
-        import torch
-        have = torch.cuda.device_count()
-        if have < n:
+        fake = os.environ.get("MSM_BENCH_FAKE_GPU_COUNT")
+        have = int(fake) if fake else count_gpus_sysfs()
+        if have is not None and have < n:
             print(f"bench.py: --gpus {n} asks for {n} ranks over RCCL but this node shows {have} GPU(s); "
                   "(MSM_BENCH_BACKEND=gloo rehearses the N > 1 path with ranks sharing GPUs)", file=sys.stderr)
+            assert "torch" not in sys.modules, "the launcher must not import torch"
             return 2
+    assert "torch" not in sys.modules and "msm_amd" not in sys.modules, "the launcher must not import torch or the engine"
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
@@ -167,6 +194,8 @@ def main():
     backend = os.environ.get("MSM_BENCH_BACKEND", "nccl")
     ngpu = torch.cuda.device_count()
     gpu_index = local_rank if backend == "nccl" else local_rank % max(1, ngpu)
+    if gpu_index >= ngpu:
+        sys.exit(f"bench.py: rank {rank} (LOCAL_RANK {local_rank}) has no GPU: this node shows {ngpu} GPU(s); refusing to run a mislabelled job")
     if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -254,6 +283,7 @@ def main():
                 if rank == 0:
                     print("bench.py: exchanging through torch.distributed on every rank", file=sys.stderr)
     cabi = bool(exchange and exchange.startswith("C ABI"))
+    rccl_ranks = eng.dist_comm_count()[0] if cabi else (dist.get_world_size() if sharded else None)     # ncclCommCount of the engine's own communicator
     if cabi and args.prepared:
         exchange = "C ABI: msm_amd_multiexp_dist_prepared_async / msm_amd_dist_wait (every rank the prepared table of its slice; ncclAllGather on the engine's own communicator)"
     gw = plan["gw"]
@@ -445,7 +475,7 @@ def main():
                                   **prep.info(), "prepare_s": t_prep}),
                        "parallelism": "1 GPU" if not sharded else f"{plan['gp']} point slices x {plan['gw']} window groups over {world} GPUs (every rank holds only its slice) + ONE RCCL all_gather of the partials",
                        "split": None if not sharded else {"gp": plan["gp"], "gw": plan["gw"], "points_per_rank": count},
-                       "exchange": exchange},
+                       "exchange": exchange, "rccl_ranks": rccl_ranks},
             "mode": (f"pipelined({depth}): {depth} calls in flight, every call collected inside the timed region" if pipelined else "one call at a time"),
             # the dominant kernel is integer-ALU bound: its roofline is the VALU issue rate of v_mad_u64_u32 (MADS_PER_ADD of them per
             # bucket addition, field_u.hpp / curve_u.hpp).  Peak: measured on this chip with tools/microbench/valu_rates.hip

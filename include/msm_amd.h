@@ -196,6 +196,9 @@ int msm_amd_dist_unique_id(uint8_t *out128);
 int msm_amd_dist_init(msm_amd_ctx *ctx, int rank, int world, const uint8_t *id128);
 int msm_amd_dist_destroy(msm_amd_ctx *ctx);
 int msm_amd_dist_info(const msm_amd_ctx *ctx, int *rank, int *world); /* world = 0: not in a group */
+/* *count = the ranks the communicator itself reports (ncclCommCount) -- what a launcher prints to show that the collective library saw
+ * every rank; *dead (may be NULL) = 1 once the group has been aborted (see msm_amd_dist_wait).  MSM_AMD_EINVAL outside a group. */
+int msm_amd_dist_comm_count(const msm_amd_ctx *ctx, int *count, int *dead);
 /* the split of a call of n points over a group of `world` ranks and the slice of the points rank `rank` = p * gw + w takes
  * (world = 0: this context's own group and rank).  With world != 0 ctx may be NULL (no GPU needed: a launcher can place the
  * slices before any context exists); a context contributes its "dist_gw" option. */

@@ -86,15 +86,17 @@ def test_planned_split_is_a_factorisation_and_covers_the_points(eng):
 
 
 def test_exchanges_follow_submission_order_whatever_the_waits_do(orc):
-    """A group of one (all a one-GPU box can hold) with four slots: G1, G2, G1, G1 calls submitted, then waited for in REVERSE order
-    from four threads.  Each wait blocks until the exchanges of the calls submitted before it are done -- the order every rank of
-    a real group shares -- and every result is right.  (With more ranks the same property keeps two promises of a Node host from
-    meeting each other's all-gather.)"""
+    """A group of one (all a one-GPU box can hold with RCCL itself; tests/test_gpu_two_ranks.py has two) with four slots: G1, G2, G1, G1
+    calls submitted, then waited for in REVERSE order -- first by ONE thread (round 4: the wait for a later ticket performs the
+    exchanges of the earlier ones on the way and parks their results; in round 3 that order blocked for ever), then from four threads
+    at once.  The exchanges themselves stay in submission order -- the order every rank of a real group shares, which keeps two
+    promises of a Node host from meeting each other's all-gather -- and every result is right."""
     import msm_amd
     eng = msm_amd.Engine(0)
     try:
         eng.set_option("slots", 4)
         eng.dist_init(0, 1, msm_amd.dist_unique_id())
+        assert eng.dist_comm_count() == (1, False)          # ncclCommCount of the engine's own communicator
         cases = []
         for k, (curve, group, n) in enumerate((("bls12381", 1, 3000), ("bls12381", 2, 700), ("bls12381", 1, 120000), ("bls12381", 1, 9))):
             bases, scalars = gu.random_case(curve, group, f"gpu:order:{k}", n)
@@ -102,26 +104,22 @@ def test_exchanges_follow_submission_order_whatever_the_waits_do(orc):
             cases.append((group, bases, scalars, n, O.normalize(O.multiexp_affine(bases, scalars, 32, n))))
         C = eng.curve("bls12381")
         tickets = [C.multiexp_dist_async(g, b, s, 32, n) for g, b, s, n, _ in cases]
-        done, got = [], [None] * 4
-        lock = threading.Lock()
+        for k in (3, 2, 1, 0):                               # one thread, newest first
+            assert tickets[k].wait() == cases[k][4], k
+        tickets = [C.multiexp_dist_async(g, b, s, 32, n) for g, b, s, n, _ in cases]
+        got = [None] * 4
 
         def waiter(k):
             got[k] = tickets[k].wait()
-            with lock:
-                done.append(k)
 
         threads = []
         for k in (3, 2, 1, 0):
             t = threading.Thread(target=waiter, args=(k,))
             t.start()
             threads.append(t)
-            if k:
-                t.join(timeout=0.3)
-                assert t.is_alive(), f"ticket {k} completed before the exchange of ticket 0"     # its turn has not come
         for t in threads:
             t.join(timeout=120)
             assert not t.is_alive()
-        assert done == [0, 1, 2, 3]
         for k, (_, _, _, _, exp) in enumerate(cases):
             assert got[k] == exp, k
         # a ticket is collected once

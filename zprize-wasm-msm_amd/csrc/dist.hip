@@ -13,6 +13,8 @@
 // Python host that has torch loaded shares torch's copy instead of bringing a second one into the process.
 #include <dlfcn.h>
 
+#include <thread>
+
 #include "engine_ctx.hpp"
 
 namespace {
@@ -24,38 +26,61 @@ struct Rccl {
     int (*CommInitRank)(void** comm, int nranks, msm_nccl_id id, int rank) = nullptr;
     int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t st) = nullptr;
     int (*CommDestroy)(void* comm) = nullptr;
+    int (*CommAbort)(void* comm) = nullptr;
+    int (*CommCount)(const void* comm, int* count) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
-    std::string why;
+    std::string why, name;
 };
+// MSM_AMD_RCCL_LIB names the library that provides the collective (default: librccl.so.1).  The tests point it at a stand-in that
+// carries the same five calls over POSIX shared memory (tests/host/fake_rccl.c), so that the multi-rank code of this file runs with
+// two real processes on a one-GPU box, which RCCL itself refuses (two ranks on one device).
 Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        const char* forced = getenv("MSM_AMD_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            r.name = forced;
+        } else {
+            for (const char* n : names) {
+                r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                r.name = n;
+                if (r.lib) break;
+            }
         }
         if (!r.lib) {
-            r.why = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+            const char* de = dlerror();
+            r.why = std::string("cannot load the collective library (") + (forced && *forced ? forced : "librccl.so.1") + "): " + (de ? de : "?");
             return;
         }
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
         r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
         r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.CommAbort = reinterpret_cast<decltype(r.CommAbort)>(dlsym(r.lib, "ncclCommAbort"));
+        r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(r.lib, "ncclCommCount"));
         r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
-            r.why = "librccl.so lacks an expected entry point";
+        if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.CommAbort || !r.GetErrorString) {
+            r.why = r.name + " lacks an expected entry point";
             r.lib = nullptr;
         }
     });
     return r;
 }
 constexpr int kNcclUint8 = 1;   // ncclUint8 (rccl.h)
-// what one rank contributes to an exchange: a 16-byte header (word 0: 0 = fine, else the negated error code of a rank whose own part
-// failed) and its Jacobian partial in 288 bytes (the largest, BLS12-381 G2).  The same size for every curve and group.
+// what one rank contributes to an exchange: a 16-byte header and its Jacobian partial in 288 bytes (the largest, BLS12-381 G2).  The
+// same size for every curve and group.  Header: word 0: 0 = fine, else the negated error code of a rank whose own part failed;
+// word 1: the split this rank planned, gp | gw << 16; word 2: the total number of points it was told; word 3: a hash of the window
+// layout of its part (0 = nothing to compare) -- Dist::Rec in engine_ctx.hpp.
 constexpr size_t kHeader = 16, kPayload = kHeader + 288;
+
+uint32_t layout_hash(int curve, int group, uint32_t scalar_size, const Geom& g) {
+    uint32_t h = 2166136261u;
+    for (uint32_t v : {(uint32_t)curve, (uint32_t)group, scalar_size, g.c, g.W, g.ns, g.nshards, g.merged}) h = (h ^ v) * 16777619u;
+    return h ? h : 1u;
+}
 
 int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
     msm_set_err(ctx, std::string(what) + ": " + rccl().GetErrorString(rc));
@@ -139,6 +164,25 @@ static bool dist_group(const msm_amd_ctx* ctx, int* rank, int* world) {
     *world = ctx->dist.world;
     return true;
 }
+// the same for an entry point that is about to queue work: a dead group refuses at once (MSM_AMD_EPEER)
+static int dist_group_alive(msm_amd_ctx* ctx, int* rank, int* world) {
+    std::string why;
+    {
+        std::lock_guard<std::mutex> dl(ctx->dist_mu);
+        if (!ctx->dist.comm) {
+            why = "multiexp_dist: msm_amd_dist_init first";
+        } else if (ctx->dist.dead) {
+            why = "multiexp_dist: this group is dead (" + ctx->dist.dead_why + "): msm_amd_dist_destroy, then a new msm_amd_dist_init on every rank";
+        } else {
+            *rank = ctx->dist.rank;
+            *world = ctx->dist.world;
+            return 0;
+        }
+    }
+    const bool dead = why.find("dead") != std::string::npos;
+    msm_set_err(ctx, why);
+    return dead ? MSM_AMD_EPEER : MSM_AMD_EINVAL;
+}
 
 extern "C" {
 
@@ -157,6 +201,10 @@ int msm_amd_dist_init(msm_amd_ctx* ctx, int rank, int world, const uint8_t* id12
     std::lock_guard<std::mutex> dl(ctx->dist_mu);   // ctx->dist is guarded by dist_mu
     if (world < 1 || rank < 0 || rank >= world || !id128) {
         msm_set_err(ctx, "dist_init: need 0 <= rank < world and the 128-byte id of rank 0's msm_amd_dist_unique_id");
+        return MSM_AMD_EINVAL;
+    }
+    if (world > 65535) {
+        msm_set_err(ctx, "dist_init: at most 65535 ranks");
         return MSM_AMD_EINVAL;
     }
     if (ctx->dist.comm) {
@@ -200,34 +248,67 @@ int msm_amd_dist_init(msm_amd_ctx* ctx, int rank, int world, const uint8_t* id12
         if (d.d_buf) (void)hipFree(d.d_buf);
         if (e != hipSuccess) {
             msm_set_err(ctx, std::string("dist_init: ") + hipGetErrorString(e));
-            return MSM_AMD_EHIP;
+            (void)hipGetLastError();
+            return e == hipErrorOutOfMemory ? MSM_AMD_ENOMEM : MSM_AMD_EHIP;
         }
         return nccl_fail(ctx, "ncclCommInitRank", nrc);
     }
     ctx->dist = std::move(d);
+    ++ctx->dist_epoch;
     return 0;
 }
 
+// Leaves the group.  Calls of the group that were submitted and never waited for are collected here (their slots would otherwise stay
+// taken for good); threads still inside msm_amd_dist_wait return MSM_AMD_EINVAL ("the group was destroyed").  An exchange that is in
+// progress is allowed to finish first -- it is bounded by the group's timeout.
 int msm_amd_dist_destroy(msm_amd_ctx* ctx) {
     if (!ctx) return MSM_AMD_EINVAL;
-    std::lock_guard<std::mutex> dl(ctx->dist_mu);
+    std::unique_lock<std::mutex> dl(ctx->dist_mu);
     if (!ctx->dist.comm) return 0;
+    ctx->dist_cv.wait(dl, [&] { return !ctx->dist.exchanging; });
+    if (!ctx->dist.comm) return 0;   // (another thread destroyed it meanwhile)
+    // calls whose partial is still with the engine (never waited for, or waiting for a turn that will not come): collect them into a
+    // scratch buffer -- only the holder of the turn takes partials from the engine, and the turn is free here
+    std::vector<uint64_t> orphans;
+    for (auto& kv : ctx->dist.recs)
+        if (kv.second.rc == 0 && !kv.second.collected) orphans.push_back(kv.second.engine_ticket);
     (void)hipSetDevice(ctx->device);
     if (ctx->dist.stream) {
         (void)hipStreamSynchronize(ctx->dist.stream);
         (void)hipStreamDestroy(ctx->dist.stream);
     }
-    (void)rccl().CommDestroy(ctx->dist.comm);
+    if (!ctx->dist.comm_gone) (void)rccl().CommDestroy(ctx->dist.comm);
     if (ctx->dist.d_buf) (void)hipFree(ctx->dist.d_buf);
     if (ctx->dist.h_buf) (void)hipHostFree(ctx->dist.h_buf);
     ctx->dist = msm_amd_ctx::Dist{};
+    ++ctx->dist_epoch;
+    dl.unlock();
     ctx->dist_cv.notify_all();
+    uint8_t scratch[288];
+    for (uint64_t t : orphans) (void)msm_amd_wait(ctx, t, scratch);
     return 0;
 }
 
 int msm_amd_dist_info(const msm_amd_ctx* ctx, int* rank, int* world) {
     if (!ctx || !rank || !world) return MSM_AMD_EINVAL;
     if (!dist_group(ctx, rank, world)) *rank = *world = 0;
+    return 0;
+}
+
+// Ranks the communicator itself counts (ncclCommCount): what a launcher prints to show that the collective library saw all of them.
+// *dead = 1 once the group has been aborted.
+int msm_amd_dist_comm_count(const msm_amd_ctx* ctx, int* count, int* dead) {
+    if (!ctx || !count) return MSM_AMD_EINVAL;
+    std::lock_guard<std::mutex> dl(ctx->dist_mu);
+    *count = 0;
+    if (dead) *dead = ctx->dist.dead ? 1 : 0;
+    if (!ctx->dist.comm) return MSM_AMD_EINVAL;
+    if (ctx->dist.comm_gone || ctx->dist.exchanging) {   // (the communicator is gone, or busy on another thread: the world it was created with)
+        *count = ctx->dist.world;
+        return 0;
+    }
+    Rccl& r = rccl();
+    if (!r.CommCount || r.CommCount(ctx->dist.comm, count) != 0) *count = ctx->dist.world;
     return 0;
 }
 
@@ -257,14 +338,20 @@ namespace {
 // group's sequence of exchanges.  A part that cannot be queued (bad argument, HIP failure, no free slot) still gets a ticket and a
 // place: the other ranks WILL enter the collective of this call, so this rank has to as well (with a failure mark, see dist_wait).
 int dist_submit(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size, uint32_t count,
-                uint32_t w, uint32_t gw, uint64_t* ticket, int refused_rc = 0, const std::string& refused_why = std::string(),
+                uint32_t w, uint32_t gw, uint32_t gp, uint32_t n_total, uint64_t* ticket, int refused_rc = 0, const std::string& refused_why = std::string(),
                 msm_amd_bases* prepared = nullptr) {
     // (dist_mu is held across the submission so that two threads cannot take sequence numbers in one order and engine tickets in
     // the other; the submission itself only queues GPU work)
     std::lock_guard<std::mutex> dl(ctx->dist_mu);
+    if (!ctx->dist.comm || ctx->dist.dead) {   // (destroyed or died between the entry point's check and here)
+        msm_set_err(ctx, ctx->dist.comm ? "multiexp_dist: this group is dead (" + ctx->dist.dead_why + ")" : std::string("multiexp_dist: msm_amd_dist_init first"));
+        return ctx->dist.comm ? MSM_AMD_EPEER : MSM_AMD_EINVAL;
+    }
     msm_amd_ctx::Dist::Rec rec;
     rec.curve = curve;
     rec.group = group;
+    rec.split = gp | (gw << 16);
+    rec.n_total = n_total;
     if (refused_rc) {   // the entry point has already found the call unusable on this rank
         rec.rc = refused_rc;
         rec.err = refused_why;
@@ -273,12 +360,68 @@ int dist_submit(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const vo
         rec.rc = prepared ? msm_amd_multiexp_prepared_async(ctx, prepared, flags, scalars, scalar_size, count, &rec.engine_ticket)
                           : msm_amd_multiexp_shard_async(ctx, curve, group, flags, bases, scalars, scalar_size, count, w, gw, &rec.engine_ticket);
         if (rec.rc) rec.err = msm_amd_last_error(ctx);
+        Geom g;
+        if (!rec.rc && !prepared && msm_ticket_geom(ctx, rec.engine_ticket, &g)) rec.layout = layout_hash(curve, group, scalar_size, g);
     }
     rec.seq = ctx->dist.next_seq++;
     const uint64_t id = ctx->dist.next_id++;
     ctx->dist.recs[id] = rec;
     *ticket = id;
     return 0;
+}
+
+bool bad_kind(msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size) {
+    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || scalar_size < 1 || scalar_size > 64) {
+        msm_set_err(ctx, "multiexp_dist: bad curve / group / scalar_size");
+        return true;   // (the same on every rank: nothing was queued anywhere)
+    }
+    return false;
+}
+
+// One exchange on the group's stream, bounded: the staged 304 bytes go up, ONE all-gather, world x 304 bytes come down.  Runs OUTSIDE
+// dist_mu (the caller holds the group's turn: `exchanging`).  Returns 0, or an error with `why` set; *aborted = true when the
+// communicator had to be aborted (a peer that never arrived, a failure of the collective itself): it is gone then.
+int exchange_once(msm_amd_ctx* ctx, void* comm, hipStream_t st, uint8_t* d, uint8_t* h, int world, uint32_t timeout_ms, std::string* why, bool* aborted) {
+    *aborted = false;
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        *why = "dist_wait: hipSetDevice failed";
+        (void)hipGetLastError();
+        return MSM_AMD_EHIP;
+    }
+    Rccl& r = rccl();
+    hipError_t e = hipMemcpyAsync(d, h, kPayload, hipMemcpyHostToDevice, st);
+    int nrc = 0;
+    if (e == hipSuccess) nrc = r.AllGather(d, d + kPayload, kPayload, kNcclUint8, comm, st);
+    if (e == hipSuccess && nrc == 0) e = hipMemcpyAsync(h + kPayload, d + kPayload, kPayload * (size_t)world, hipMemcpyDeviceToHost, st);
+    // wait for the stream, but not for ever: a peer that died, or never submitted this call, would leave this rank in the collective.
+    // The exchange itself takes ~50 us: poll closely for the first milliseconds, then every 200 us.
+    bool timed_out = false;
+    hipError_t q = hipSuccess;
+    if (e == hipSuccess && nrc == 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            q = hipStreamQuery(st);
+            if (q != hipErrorNotReady) break;
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (timeout_ms && ms > (double)timeout_ms) {
+                timed_out = true;
+                break;
+            }
+            if (ms > 5.0) std::this_thread::sleep_for(std::chrono::microseconds(200));
+        }
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error to keep)
+    }
+    if (e == hipSuccess && nrc == 0 && !timed_out && q == hipSuccess) return 0;
+    // something went wrong on this side or a peer did not come: abort the communicator so that whatever it queued leaves the stream,
+    // then drain the stream -- after this the group is dead on this rank, and the peers find out through their own timeouts
+    if (timed_out) *why = "dist_wait: the exchange did not complete within " + std::to_string(timeout_ms) + " ms (a rank of the group died, or never submitted this call; option \"dist_timeout_ms\")";
+    else if (nrc != 0) *why = std::string("ncclAllGather: ") + r.GetErrorString(nrc);
+    else *why = std::string("dist_wait: ") + hipGetErrorString(e != hipSuccess ? e : q);
+    (void)r.CommAbort(comm);
+    *aborted = true;
+    (void)hipStreamSynchronize(st);
+    (void)hipGetLastError();
+    return timed_out ? MSM_AMD_EPEER : MSM_AMD_EHIP;
 }
 
 }  // namespace
@@ -290,21 +433,15 @@ int msm_amd_multiexp_dist_async(msm_amd_ctx* ctx, int curve, int group, uint32_t
                                 uint32_t n, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
     int my_rank = 0, world = 0;
-    if (!dist_group(ctx, &my_rank, &world)) {
-        msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
-        return MSM_AMD_EINVAL;
-    }
-    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || scalar_size < 1 || scalar_size > 64) {
-        msm_set_err(ctx, "multiexp_dist: bad curve / group / scalar_size");
-        return MSM_AMD_EINVAL;   // (the same on every rank: nothing was queued anywhere)
-    }
+    if (int rc = dist_group_alive(ctx, &my_rank, &world)) return rc;
+    if (bad_kind(ctx, curve, group, scalar_size)) return MSM_AMD_EINVAL;
     uint32_t gp, gw, first, count;
     msm_dist_split(ctx, curve, group, scalar_size, n, (uint32_t)world, &gp, &gw);
     msm_dist_slice(n, gp, (uint32_t)my_rank / gw, &first, &count);
     const size_t bstride = (size_t)((flags & MSM_AMD_BASES_JACOBIAN) ? 3 : 2) * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group;
     const uint8_t* b = bases ? (const uint8_t*)bases + (size_t)first * bstride : nullptr;
     const uint8_t* s = scalars ? (const uint8_t*)scalars + (size_t)first * scalar_size : nullptr;
-    return dist_submit(ctx, curve, group, flags, b, s, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket);
+    return dist_submit(ctx, curve, group, flags, b, s, scalar_size, count, (uint32_t)my_rank % gw, gw, gp, n, ticket);
 }
 
 // This rank holds only ITS slice of the n_total points (msm_amd_dist_plan says which): bases_local / scalars_local are that slice.
@@ -312,14 +449,8 @@ int msm_amd_multiexp_dist_local_async(msm_amd_ctx* ctx, int curve, int group, ui
                                       uint32_t scalar_size, uint32_t n_local, uint32_t n_total, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
     int my_rank = 0, world = 0;
-    if (!dist_group(ctx, &my_rank, &world)) {
-        msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
-        return MSM_AMD_EINVAL;
-    }
-    if ((curve != MSM_AMD_BLS12381 && curve != MSM_AMD_BN128) || (group != 1 && group != 2) || scalar_size < 1 || scalar_size > 64) {
-        msm_set_err(ctx, "multiexp_dist: bad curve / group / scalar_size");
-        return MSM_AMD_EINVAL;
-    }
+    if (int rc = dist_group_alive(ctx, &my_rank, &world)) return rc;
+    if (bad_kind(ctx, curve, group, scalar_size)) return MSM_AMD_EINVAL;
     uint32_t gp, gw, first, count;
     msm_dist_split(ctx, curve, group, scalar_size, n_total, (uint32_t)world, &gp, &gw);
     msm_dist_slice(n_total, gp, (uint32_t)my_rank / gw, &first, &count);
@@ -329,26 +460,108 @@ int msm_amd_multiexp_dist_local_async(msm_amd_ctx* ctx, int curve, int group, ui
         // is -- so this rank still takes part in the exchange, with a failure mark.
         const std::string why = "multiexp_dist_local: n_local = " + std::to_string(n_local) + " but this rank's slice of " + std::to_string(n_total) +
                                 " points is " + std::to_string(count) + " (msm_amd_dist_plan; were options changed in between?)";
-        return dist_submit(ctx, curve, group, flags, nullptr, nullptr, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket, MSM_AMD_EINVAL, why);
+        return dist_submit(ctx, curve, group, flags, nullptr, nullptr, scalar_size, count, (uint32_t)my_rank % gw, gw, gp, n_total, ticket, MSM_AMD_EINVAL, why);
     }
-    return dist_submit(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, count, (uint32_t)my_rank % gw, gw, ticket);
+    return dist_submit(ctx, curve, group, flags, bases_local, scalars_local, scalar_size, count, (uint32_t)my_rank % gw, gw, gp, n_total, ticket);
 }
 
-// Waits for this rank's partial, takes part in the exchange of this call (one ncclAllGather of world x 304 bytes: a status word and
-// the Jacobian partial of every rank) and writes the normalised sum -- the same bytes on every rank.
-// The exchanges of a context happen in the order in which its calls were SUBMITTED, whatever the order (and the threads) in which they
-// are waited for: every rank submits the same calls in the same order, so the collectives match -- two promises resolved by two
-// libuv workers cannot cross, and a G1 call cannot meet a G2 call.  Every ticket must be waited for (a later one waits its turn).
+}  // extern "C"
+
+namespace {
+
+// The exchange of ONE call of the group -- `rec`, the head of the sequence -- by the thread that holds the turn (`exchanging`), outside
+// dist_mu: this rank's partial is taken from the engine, the headers and partials cross in one bounded all-gather, the headers are
+// compared, the partials added.  Fills rec.out_rc / out_err / out; returns != 0 (with *why, *aborted) only when the GROUP has failed.
+int exchange_call(msm_amd_ctx* ctx, msm_amd_ctx::Dist::Rec& rec, void* comm, hipStream_t st, uint8_t* d, uint8_t* h, int world, uint32_t timeout_ms,
+                  std::string* why, bool* aborted) {
+    const size_t jsz = (size_t)3 * (rec.curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)rec.group;
+    uint8_t mine[kPayload] = {};
+    int rc_local = rec.rc;
+    std::string err_local = rec.err;
+    if (rc_local == 0) {
+        rc_local = msm_amd_wait(ctx, rec.engine_ticket, mine + kHeader);
+        if (rc_local) err_local = msm_amd_last_error(ctx);
+        rec.collected = true;
+    }
+    if (rc_local) {   // the point at infinity and the mark
+        memset(mine, 0, sizeof mine);
+        const uint32_t mark = (uint32_t)(-rc_local);
+        memcpy(mine, &mark, 4);
+    }
+    memcpy(mine + 4, &rec.split, 4);
+    memcpy(mine + 8, &rec.n_total, 4);
+    memcpy(mine + 12, &rec.layout, 4);
+    memcpy(h, mine, kPayload);
+    if (int rc = exchange_once(ctx, comm, st, d, h, world, timeout_ms, why, aborted)) {
+        rec.out_rc = rc_local ? rc_local : rc;
+        rec.out_err = rc_local ? err_local : *why;
+        return rc;
+    }
+    std::vector<uint8_t> parts((size_t)world * jsz);
+    std::vector<uint32_t> hdr((size_t)world * 4);
+    int failed_rank = -1;
+    for (int k = 0; k < world; ++k) {
+        memcpy(&hdr[(size_t)k * 4], h + kPayload * (size_t)(k + 1), 16);
+        if (hdr[(size_t)k * 4] && failed_rank < 0) failed_rank = k;
+        memcpy(parts.data() + (size_t)k * jsz, h + kPayload * (size_t)(k + 1) + kHeader, jsz);
+    }
+    // every rank compares every header with every other, so that all of them reach the same verdict
+    std::string disagree;
+    const uint32_t gw = std::max(1u, rec.split >> 16);
+    for (int k = 0; k < world && disagree.empty(); ++k) {
+        const uint32_t* a = &hdr[(size_t)k * 4];
+        for (int j = k + 1; j < world && disagree.empty(); ++j) {
+            const uint32_t* b = &hdr[(size_t)j * 4];
+            if (a[1] != b[1] || a[2] != b[2])
+                disagree = "ranks " + std::to_string(k) + " and " + std::to_string(j) + " planned different splits of this call (" + std::to_string(a[1] & 0xffff) + " x " +
+                           std::to_string(a[1] >> 16) + " of " + std::to_string(a[2]) + " points against " + std::to_string(b[1] & 0xffff) + " x " + std::to_string(b[1] >> 16) +
+                           " of " + std::to_string(b[2]) + "): the same options (\"dist_gw\") and arguments on every rank";
+            else if ((uint32_t)k / gw == (uint32_t)j / gw && a[3] && b[3] && !a[0] && !b[0] && a[3] != b[3])
+                disagree = "ranks " + std::to_string(k) + " and " + std::to_string(j) + " share a point slice but use different window layouts: the same options "
+                           "(\"window_bits\", \"even_windows\") on every rank";
+        }
+    }
+    if (rc_local) {
+        rec.out_rc = rc_local;
+        rec.out_err = err_local;
+    } else if (failed_rank >= 0) {
+        rec.out_rc = MSM_AMD_EPEER;
+        rec.out_err = "multiexp_dist: rank " + std::to_string(failed_rank) + " of the group failed its part of this call (its own error text says why)";
+    } else if (!disagree.empty()) {
+        rec.out_rc = MSM_AMD_EINVAL;
+        rec.out_err = "multiexp_dist: " + disagree;
+    } else {
+        rec.out.resize(jsz);
+        rec.out_rc = msm_amd_combine(rec.curve, rec.group, parts.data(), (uint32_t)world, rec.out.data());
+        if (rec.out_rc) rec.out_err = "multiexp_dist: combining the partials failed";
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Takes part in the exchange of this call (one ncclAllGather of world x 304 bytes: a header and the Jacobian partial of every rank) and
+// writes the normalised sum -- the same bytes on every rank.
+// The exchanges of a context happen in the order in which its calls were SUBMITTED, on every rank: every rank submits the same calls
+// in the same order, so the collectives match -- two promises resolved by two libuv workers cannot cross, and a G1 call cannot meet a G2
+// call.  The tickets may be WAITED FOR in any order and from any threads: a thread that asks for a later ticket performs the exchanges
+// of the earlier ones first and parks their results for whoever asks for them (every ticket must still be waited for, or the group
+// left with msm_amd_dist_destroy).
 // A rank whose own part failed still takes part, with a failure mark: it returns its error, the others MSM_AMD_EPEER.
+// The exchange itself runs outside dist_mu (only the turn is held), and it is bounded: after `dist_timeout_ms` without the peers, or on
+// a failure of the collective, the communicator is aborted and the group is dead -- this and every later call return an error at once.
+// The headers are compared: ranks that planned different splits, or different window layouts inside one point slice, get MSM_AMD_EINVAL
+// on every rank instead of a sum of partials that do not belong together.
 int msm_amd_dist_wait(msm_amd_ctx* ctx, int curve, int group, uint64_t ticket, uint8_t* out) {
     if (!ctx || !out) return MSM_AMD_EINVAL;
-    msm_amd_ctx::Dist::Rec rec;
+    std::unique_lock<std::mutex> dl(ctx->dist_mu);
+    if (!ctx->dist.comm) {
+        msm_set_err(ctx, "dist_wait: msm_amd_dist_init first");
+        return MSM_AMD_EINVAL;
+    }
     {
-        std::lock_guard<std::mutex> dl(ctx->dist_mu);
-        if (!ctx->dist.comm) {
-            msm_set_err(ctx, "dist_wait: msm_amd_dist_init first");
-            return MSM_AMD_EINVAL;
-        }
         auto it = ctx->dist.recs.find(ticket);
         if (it == ctx->dist.recs.end() || it->second.waiting) {
             msm_set_err(ctx, "dist_wait: unknown or already collected ticket");
@@ -359,72 +572,80 @@ int msm_amd_dist_wait(msm_amd_ctx* ctx, int curve, int group, uint64_t ticket, u
             return MSM_AMD_EINVAL;
         }
         it->second.waiting = true;
-        rec = it->second;
     }
-    const size_t jsz = (size_t)3 * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group;
-    uint8_t mine[kPayload] = {};
-    int rc_local = rec.rc;
-    std::string err_local = rec.err;
-    if (rc_local == 0) {
-        rc_local = msm_amd_wait(ctx, rec.engine_ticket, mine + kHeader);   // outside dist_mu: other calls are submitted and waited for meanwhile
-        if (rc_local) err_local = msm_amd_last_error(ctx);
-    }
-    if (rc_local) {   // the point at infinity and the mark
-        memset(mine, 0, sizeof mine);
-        const uint32_t mark = (uint32_t)(-rc_local);
-        memcpy(mine, &mark, 4);
-    }
-    std::unique_lock<std::mutex> dl(ctx->dist_mu);
-    ctx->dist_cv.wait(dl, [&] { return !ctx->dist.comm || ctx->dist.next_exchange == rec.seq; });
-    if (!ctx->dist.comm) {
-        msm_set_err(ctx, "dist_wait: the group was destroyed while a call was waiting for its exchange");
-        return MSM_AMD_EINVAL;
-    }
-    int rc = 0;
-    const int world = ctx->dist.world;
-    uint8_t* d = (uint8_t*)ctx->dist.d_buf;
-    uint8_t* h = (uint8_t*)ctx->dist.h_buf;
-    do {
-        if (hipSetDevice(ctx->device) != hipSuccess) { rc = MSM_AMD_EHIP; msm_set_err(ctx, "dist_wait: hipSetDevice failed"); break; }
-        memcpy(h, mine, kPayload);
-        hipError_t e = hipMemcpyAsync(d, h, kPayload, hipMemcpyHostToDevice, ctx->dist.stream);
-        int nrc = 0;
-        if (e == hipSuccess) nrc = rccl().AllGather(d, d + kPayload, kPayload, kNcclUint8, ctx->dist.comm, ctx->dist.stream);
-        if (e == hipSuccess && nrc == 0) e = hipMemcpyAsync(h + kPayload, d + kPayload, kPayload * (size_t)world, hipMemcpyDeviceToHost, ctx->dist.stream);
-        const hipError_t e2 = hipStreamSynchronize(ctx->dist.stream);
-        if (nrc != 0) { rc = nccl_fail(ctx, "ncclAllGather", nrc); break; }
-        if (e != hipSuccess || e2 != hipSuccess) {
-            rc = MSM_AMD_EHIP;
-            msm_set_err(ctx, std::string("dist_wait: ") + hipGetErrorString(e != hipSuccess ? e : e2));
-            break;
+    const uint64_t epoch = ctx->dist_epoch;
+    for (;;) {
+        if (ctx->dist_epoch != epoch) {   // (the records went with the group)
+            msm_set_err(ctx, "dist_wait: the group was destroyed while a call was waiting for its exchange");
+            return MSM_AMD_EINVAL;
         }
-    } while (0);
-    // this call's turn is over whatever happened: the next one may go
-    ++ctx->dist.next_exchange;
-    ctx->dist.recs.erase(ticket);
-    std::vector<uint8_t> parts;
-    int failed_rank = -1;
-    if (rc == 0) {
-        parts.resize((size_t)world * jsz);
-        for (int k = 0; k < world; ++k) {
-            uint32_t mark;
-            memcpy(&mark, h + kPayload * (size_t)(k + 1), 4);
-            if (mark && failed_rank < 0) failed_rank = k;
-            memcpy(parts.data() + (size_t)k * jsz, h + kPayload * (size_t)(k + 1) + kHeader, jsz);
+        auto it = ctx->dist.recs.find(ticket);   // (present: only this thread erases it)
+        msm_amd_ctx::Dist::Rec& mine = it->second;
+        if (mine.done) {
+            const int rc = mine.out_rc;
+            const std::string err = mine.out_err;
+            if (rc == 0) memcpy(out, mine.out.data(), mine.out.size());
+            ctx->dist.recs.erase(it);
+            dl.unlock();
+            if (rc) msm_set_err(ctx, err);
+            return rc;
         }
+        if (ctx->dist.dead) {
+            // no exchange will happen any more: free this call's slot and report
+            const bool collect = mine.rc == 0 && !mine.collected;
+            const uint64_t et = mine.engine_ticket;
+            const int rc_local = mine.rc;
+            const std::string why = ctx->dist.dead_why;
+            ctx->dist.recs.erase(it);
+            dl.unlock();
+            uint8_t scratch[288];
+            if (collect) (void)msm_amd_wait(ctx, et, scratch);
+            msm_set_err(ctx, "multiexp_dist: this group is dead (" + why + "): msm_amd_dist_destroy, then a new msm_amd_dist_init on every rank");
+            return rc_local ? rc_local : MSM_AMD_EPEER;
+        }
+        if (ctx->dist.exchanging) {
+            ctx->dist_cv.wait(dl);
+            continue;
+        }
+        // the turn is free: perform the exchange at the head of the sequence -- this ticket's or an earlier one's
+        uint64_t head_id = 0;
+        for (auto& kv : ctx->dist.recs)
+            if (!kv.second.done && kv.second.seq == ctx->dist.next_exchange) head_id = kv.first;
+        if (!head_id) {   // cannot happen: this ticket itself is not done, so the sequence has not passed it
+            msm_set_err(ctx, "dist_wait: internal error (no call at the head of the sequence)");
+            ctx->dist.recs.erase(it);
+            return MSM_AMD_EHIP;
+        }
+        ctx->dist.exchanging = true;
+        msm_amd_ctx::Dist::Rec head = ctx->dist.recs[head_id];
+        void* comm = ctx->dist.comm;
+        hipStream_t st = ctx->dist.stream;
+        const int world = ctx->dist.world;
+        uint8_t* d = (uint8_t*)ctx->dist.d_buf;
+        uint8_t* h = (uint8_t*)ctx->dist.h_buf;
+        const uint32_t timeout_ms = ctx->dist_timeout_ms.load();
+        dl.unlock();
+        std::string why;
+        bool aborted = false;
+        const int grc = exchange_call(ctx, head, comm, st, d, h, world, timeout_ms, &why, &aborted);
+        dl.lock();
+        ctx->dist.exchanging = false;
+        if (ctx->dist_epoch == epoch) {   // (a destroy waits for the turn to be handed back, so this always holds; kept as a guard)
+            ++ctx->dist.next_exchange;
+            head.done = true;
+            auto hit = ctx->dist.recs.find(head_id);
+            if (hit != ctx->dist.recs.end()) {
+                head.waiting = hit->second.waiting;   // (someone may have started to wait for it meanwhile)
+                hit->second = std::move(head);
+            }
+            if (grc) {
+                ctx->dist.dead = true;
+                ctx->dist.comm_gone = aborted;
+                ctx->dist.dead_why = why;
+            }
+        }
+        ctx->dist_cv.notify_all();
     }
-    dl.unlock();
-    ctx->dist_cv.notify_all();
-    if (rc) return rc;
-    if (rc_local) {
-        msm_set_err(ctx, err_local);
-        return rc_local;
-    }
-    if (failed_rank >= 0) {
-        msm_set_err(ctx, "multiexp_dist: rank " + std::to_string(failed_rank) + " of the group failed its part of this call (its own error text says why)");
-        return MSM_AMD_EPEER;
-    }
-    return msm_amd_combine(curve, group, parts.data(), (uint32_t)world, out);
 }
 
 int msm_amd_multiexp_dist(msm_amd_ctx* ctx, int curve, int group, uint32_t flags, const void* bases, const void* scalars, uint32_t scalar_size,
@@ -440,12 +661,8 @@ int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* local_
                                          uint32_t n_local, uint64_t* ticket) {
     if (!ctx || !ticket) return MSM_AMD_EINVAL;
     int my_rank = 0, world = 0;
-    if (!dist_group(ctx, &my_rank, &world)) {
-        msm_set_err(ctx, "multiexp_dist: msm_amd_dist_init first");
-        return MSM_AMD_EINVAL;
-    }
+    if (int rc = dist_group_alive(ctx, &my_rank, &world)) return rc;
     (void)my_rank;
-    (void)world;
     uint32_t info[6];
     if (!local_table || msm_amd_bases_info(local_table, info, nullptr)) {
         msm_set_err(ctx, "multiexp_dist_prepared: no table");
@@ -453,7 +670,7 @@ int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* local_
     }
     int curve = 0, group = 0;
     msm_bases_kind(local_table, &curve, &group);
-    return dist_submit(ctx, curve, group, flags, nullptr, scalars_local, scalar_size, n_local, 0, 1, ticket, 0, std::string(), local_table);
+    return dist_submit(ctx, curve, group, flags, nullptr, scalars_local, scalar_size, n_local, 0, 1, (uint32_t)world, 0, ticket, 0, std::string(), local_table);
 }
 int msm_amd_multiexp_dist_prepared(msm_amd_ctx* ctx, msm_amd_bases* local_table, uint32_t flags, const void* scalars_local, uint32_t scalar_size,
                                    uint32_t n_local, uint8_t* out) {

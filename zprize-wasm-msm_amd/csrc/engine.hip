@@ -984,6 +984,17 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
     return rc;
 }
 
+bool msm_ticket_geom(msm_amd_ctx* ctx, uint64_t ticket, Geom* g) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    for (Slot& sl : ctx->slots)
+        if (sl.pending && sl.ticket == ticket) {
+            if (sl.trivial) return false;
+            *g = sl.g;
+            return true;
+        }
+    return false;
+}
+
 static size_t elem_bytes(int curve, int group) { return (size_t)(curve == MSM_AMD_BLS12381 ? 48 : 32) * (size_t)group; }
 static int dispatch(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint8_t* out) {
     if (!ctx) return MSM_AMD_EINVAL;
@@ -1151,6 +1162,7 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     }
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
+    if (const char* e = getenv("MSM_AMD_DIST_TIMEOUT_MS")) ctx->dist_timeout_ms.store((uint32_t)strtoul(e, nullptr, 10));
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -1271,6 +1283,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "hot")) { ctx->no_hot = value == 0; return 0; }   // 0 = hot buckets take the ordinary segment path (before / after measurements)
     if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return 0; }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
+    if (!strcmp(name, "dist_timeout_ms")) { ctx->dist_timeout_ms.store(value); return 0; }   // how long an exchange of a multi-GPU group waits for its peers (0 = for ever)
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
     if (!strcmp(name, "chunk_mode")) { ctx->chunk_mode = value; return 0; }     // experiments: chunk-parallel fine sort, 1 = 4096-entry chunks / 256 lanes, 2 = 8192 / 1024, 0 = by what else is in flight
     if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size

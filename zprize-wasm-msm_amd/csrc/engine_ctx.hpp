@@ -127,12 +127,32 @@ struct msm_amd_ctx {
             int rc = 0;          // != 0: this rank's part could not even be queued; it still takes part in the exchange, with a failure mark
             std::string err;
             bool waiting = false;
+            // what this rank believes about the call, sent in the exchange's header and compared across ranks (a disagreement -- options
+            // that differ between ranks -- would otherwise add partials of different splits into a silently wrong point):
+            // gp | gw << 16, the total number of points (0: prepared tables, whose slices need not tile anything), a hash of the window
+            // layout of this rank's part (0: nothing to compare -- an empty part)
+            uint32_t split = 0, n_total = 0, layout = 0;
+            // Exchanges happen in submission order, tickets may be waited for in ANY order: a thread that waits for a later ticket performs
+            // the exchanges of the earlier ones on the way and parks their outcome here for whoever asks for them
+            bool collected = false;   // this rank's own partial has been taken from the engine (its slot is free)
+            bool done = false;        // the exchange of this call has happened: out_rc / out_err / out are final
+            int out_rc = 0;
+            std::string out_err;
+            std::vector<uint8_t> out;   // the normalised sum (3 field elements)
         };
         std::map<uint64_t, Rec> recs;   // by dist ticket
         uint64_t next_id = 1, next_seq = 0, next_exchange = 0;
+        bool exchanging = false;   // a thread has taken its turn and is inside the collective -- OUTSIDE dist_mu; staging, stream and comm are its alone
+        // A group is DEAD once an exchange has failed locally or timed out (a peer that never entered): the communicator has been
+        // aborted (ncclCommAbort), every pending and every later call of the group returns MSM_AMD_EPEER at once instead of blocking,
+        // and the only way on is msm_amd_dist_destroy (+ a new msm_amd_dist_init).
+        bool dead = false, comm_gone = false;   // comm_gone: the communicator was aborted -- nothing left to destroy
+        std::string dead_why;
     } dist;
     mutable std::mutex dist_mu;
-    std::condition_variable dist_cv;   // next_exchange moved on
+    std::condition_variable dist_cv;   // next_exchange moved on, an exchange ended, the group died or was destroyed
+    uint64_t dist_epoch = 0;           // bumped by dist_init / dist_destroy (under dist_mu): a waiter that slept through a destroy + init must not take the new group for its own
+    std::atomic<uint32_t> dist_timeout_ms{300000};   // option "dist_timeout_ms" / MSM_AMD_DIST_TIMEOUT_MS: how long an exchange may wait for the peers (0 = for ever)
     std::vector<msm_amd_bases*> prepared_handles;   // handles this context has prepared and not released (guarded by mu): freed by msm_amd_destroy
     int even_windows = 1;              // option "even_windows": windows of c and c - 1 bits that tile the scalar exactly when c does not divide its width
     uint32_t dist_gw = 0;              // option "dist_gw": window groups of a sharded call (0 = chosen per call; must divide the world size)
@@ -175,7 +195,10 @@ struct msm_amd_ctx {
 // so it is guarded by its own small lock, and msm_amd_last_error hands out a per-thread copy.
 void msm_set_err(msm_amd_ctx* ctx, const std::string& msg);
 
-// The split of a call of n points over `world` ranks (engine.hip): gp point slices x gw window groups, gp * gw = world.
+// Window layout of the call behind an engine ticket that has been submitted and not yet collected (engine.hip); false: no such
+// ticket, or a call without GPU work (n = 0)
+bool msm_ticket_geom(msm_amd_ctx* ctx, uint64_t ticket, Geom* g);
+// The split of a call of n points over `world` ranks (dist.hip): gp point slices x gw window groups, gp * gw = world.
 void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scalar_size, uint32_t n, uint32_t world, uint32_t* gp, uint32_t* gw);
 // Slice p of gp: points [first, first + count) -- equal slices of ceil(n / gp), the last ones shorter or empty.
 inline void msm_dist_slice(uint32_t n, uint32_t gp, uint32_t p, uint32_t* first, uint32_t* count) {

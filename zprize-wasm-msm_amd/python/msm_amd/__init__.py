@@ -84,6 +84,7 @@ def load_library(path=None):
     L.msm_amd_dist_init.argtypes = [vp, c.c_int, c.c_int, vp]
     L.msm_amd_dist_destroy.argtypes = [vp]
     L.msm_amd_dist_info.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]
+    L.msm_amd_dist_comm_count.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_int)]
     L.msm_amd_multiexp_dist.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, u8p]
     L.msm_amd_multiexp_dist_async.argtypes = [vp, c.c_int, c.c_int, u32, vp, vp, u32, u32, c.POINTER(c.c_uint64)]
     L.msm_amd_dist_wait.argtypes = [vp, c.c_int, c.c_int, c.c_uint64, u8p]
@@ -244,6 +245,12 @@ class Engine:
         r, w = ctypes.c_int(), ctypes.c_int()
         self._chk(self.L.msm_amd_dist_info(self.ctx, ctypes.byref(r), ctypes.byref(w)))
         return r.value, w.value
+
+    def dist_comm_count(self):
+        """(ranks the communicator itself counts -- ncclCommCount --, whether the group has been aborted)"""
+        n, dead = ctypes.c_int(), ctypes.c_int()
+        self._chk(self.L.msm_amd_dist_comm_count(self.ctx, ctypes.byref(n), ctypes.byref(dead)))
+        return n.value, bool(dead.value)
 
     def dist_plan(self, curve, group, scalar_size, n, world=0, rank=0):
         """msm_amd_dist_plan: how a call of n points is split over a group of `world` ranks (0: this engine's own group and rank) --
