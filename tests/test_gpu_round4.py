@@ -1,0 +1,177 @@
+"""GPU tests added in round 4 (run with -m gpu on the MI355X box):
+  * the accumulation's work list (k_items_plan / k_accumulate_items / k_join_items: lanes per bucket in proportion to its population,
+    csrc/bucket_kernels.hpp) against the oracle -- every curve and group, forced on at window sizes and lane lengths that exercise one
+    lane per bucket, several lanes per bucket, the open-ended top population class, coarser population classes (osh > 0), skewed and
+    hot buckets whose rest goes to the tail kernels, sharded and prepared calls;
+  * a prepared table released while another thread submits on it, released twice, used after release.
+Reference semantics under test: wasmcurves/src/build_multiexp.js:186-233 (every (scalar, point) pair lands in exactly one bucket of
+every window) -- the work list only changes which lane adds which entries."""
+import random
+import threading
+
+import pytest
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc(oracle_lib):
+    return oracle_lib
+
+
+def _f(C, group):
+    return C.g1m_multiexpAffine if group == 1 else C.g2m_multiexpAffine
+
+
+@pytest.mark.parametrize("curve,group,n,c,t", [
+    ("bls12381", 1, 70000, 0, 0),      # the engine's own choice at a size where the work list is the default path
+    ("bls12381", 1, 70000, 14, 8),     # mean 8.5 at T = 8: about half the buckets on two lanes
+    ("bls12381", 1, 20000, 9, 16),     # 256 buckets per window, mean 78: every bucket on several lanes, some on all eight (rest -> tail kernels)
+    ("bls12381", 1, 50000, 12, 200),   # T = 200: population classes in steps of two (8 T > 1023)
+    ("bls12381", 1, 3000, 11, 8),      # most buckets hold 2-3 entries, many are empty
+    ("bn128", 1, 120000, 13, 0),
+    ("bn128", 1, 9000, 10, 8),
+    ("bls12381", 2, 12000, 11, 8),     # a point on a lane pair: 32 items per wave
+    ("bn128", 2, 5000, 9, 8),
+])
+def test_work_list_matches_the_oracle(orc, curve, group, n, c, t):
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("items", 1)
+        if c:
+            eng.set_window_bits(c)
+        if t:
+            eng.set_option("items_t", t)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, f"gpu:items:{curve}:{group}:{n}:{c}", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        assert _f(C, group)(bases, scalars, 32, n) == exp
+        # two in flight (the second call's sort runs under the first one's work list), and the same call with the work list off
+        t1, t2 = C.multiexp_async(group, bases, scalars, 32, n), C.multiexp_async(group, bases, scalars, 32, n)
+        assert t1.wait() == exp and t2.wait() == exp
+        eng.set_option("items", 2)
+        assert _f(C, group)(bases, scalars, 32, n) == exp
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 60000), ("bn128", 1, 30000), ("bls12381", 2, 8000)])
+def test_work_list_with_skewed_scalars(orc, curve, group, n):
+    """Populations far from uniform under the work list: a witness-like mix (one bucket of window 0 holds most points: it gets its eight
+    lanes and the rest is queued as a HOT bucket for the tail kernels), a few dozen distinct scalars (a handful of very long buckets
+    per window, all the others empty), every scalar equal, and 64-bit values (every window above the fourth empty)."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("items", 1)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, uniform = gu.random_case(curve, group, f"gpu:items-skew:{curve}:{group}:{n}", n)
+        rnd = random.Random(n)
+        witness = bytearray(uniform)
+        for i in range(n):
+            r = rnd.random()
+            if r < 0.6:
+                witness[32 * i:32 * i + 32] = (1).to_bytes(32, "little")
+            elif r < 0.75:
+                witness[32 * i:32 * i + 32] = bytes(32)
+            elif r < 0.85:
+                witness[32 * i + 2:32 * i + 32] = bytes(30)
+        few = b"".join(uniform[32 * k:32 * k + 32] for k in (rnd.randrange(40) for _ in range(n)))
+        same = uniform[:32] * n
+        narrow = b"".join(uniform[32 * i:32 * i + 8] + bytes(24) for i in range(n))
+        for name, sc in (("witness", bytes(witness)), ("few", few), ("same", same), ("narrow", narrow)):
+            exp = O.normalize(O.multiexp_affine(bases, sc, 32, n))
+            for rep in range(2):          # (the second call runs with the skew hint the first one left)
+                assert _f(C, group)(bases, sc, 32, n) == exp, (name, rep)
+    finally:
+        eng.close()
+
+
+def test_work_list_in_sharded_and_prepared_calls(orc):
+    """The windows one rank of a sharded call owns (few buckets, dense: where the sliced launch used to serve) and a prepared table
+    (merged windows: one bucket set fed by every window) under the work list."""
+    import msm_amd
+    curve, group, n = "bls12381", 1, 90000
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("items", 1)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, "gpu:items:sharded", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        for gw in (2, 4, 8):
+            parts = b"".join(C.multiexp_shard(group, bases, scalars, 32, n, w, gw) for w in range(gw))
+            assert msm_amd.combine(curve, group, parts) == exp, gw
+        pb = C.prepare_bases(group, bases, n)
+        try:
+            assert pb.multiexp(scalars) == exp
+        finally:
+            pb.release()
+    finally:
+        eng.close()
+
+
+def test_release_of_a_prepared_table_is_atomic_with_submissions(orc):
+    """msm_amd_release_bases and the submission of a call on the table share one critical section: while one thread
+    keeps calls in flight on a table, another thread's release is refused ("still in flight") or, once it succeeds, every later call is
+    refused ("released") -- never a call on freed memory.  A second release and a call on the released handle are errors, not crashes."""
+    import msm_amd
+    curve, group, n = "bn128", 1, 20000
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("slots", 4)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, "gpu:release-race", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        pb = C.prepare_bases(group, bases, n)
+        handle = pb.handle
+        outcome = {"good": 0, "refused": 0, "bad": []}
+        stop = threading.Event()
+
+        def caller():
+            while not stop.is_set():
+                try:
+                    r = pb.multiexp(scalars)
+                    if r == exp:
+                        outcome["good"] += 1
+                    else:
+                        outcome["bad"].append("wrong result")
+                except msm_amd.MsmAmdError as e:
+                    if "released" in str(e) or "not bases of this context" in str(e):
+                        outcome["refused"] += 1
+                        return
+                    outcome["bad"].append(str(e))
+                    return
+
+        th = threading.Thread(target=caller)
+        th.start()
+        import time
+        released, refusals, t0 = False, 0, time.time()
+        while outcome["good"] < 5 and time.time() - t0 < 60:      # let a few calls through first
+            time.sleep(0.001)
+        while time.time() - t0 < 120:
+            rc = eng.L.msm_amd_release_bases(eng.ctx, handle)
+            if rc == 0:
+                released = True
+                break
+            refusals += 1
+            assert "in flight" in eng.L.msm_amd_last_error(eng.ctx).decode()
+        stop.set()
+        th.join(timeout=120)
+        assert not th.is_alive() and not outcome["bad"], outcome
+        assert released and outcome["good"] > 0
+        pb.handle = None
+        # the handle is gone: a second release and a call on it are refused without touching it
+        assert eng.L.msm_amd_release_bases(eng.ctx, handle) == msm_amd.EINVAL
+        import ctypes
+        buf = ctypes.create_string_buffer(96)
+        assert eng.L.msm_amd_multiexp_prepared(eng.ctx, handle, 0, scalars, 32, n, buf) == msm_amd.EINVAL
+        assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp        # the context is fine
+    finally:
+        eng.close()

@@ -5,4 +5,5 @@ namespace msm {
 using F_ = Fp<Bn254Fp, true>;
 MSM_INSTANTIATE_ACCUMULATE(F_, 1)
 MSM_INSTANTIATE_SLICES(F_, 1)
+MSM_INSTANTIATE_ITEMS(F_, 1)
 }  // namespace msm

@@ -7,4 +7,6 @@ using F2a_ = Fp2<Bls12381Fp>;
 using F2b_ = Fp2<Bn254Fp>;
 MSM_INSTANTIATE_REDUCE(F2a_)
 MSM_INSTANTIATE_REDUCE(F2b_)
+MSM_INSTANTIATE_JOIN_ITEMS(F2a_)   // the join of the work list: one inlined addition per lane, no private segment
+MSM_INSTANTIATE_JOIN_ITEMS(F2b_)
 }  // namespace msm

@@ -314,6 +314,88 @@ __global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __rest
     if (cnt > K * seg && sub == 0) queue_segments(ctl, work, biglist, b, cnt, K * seg, seg, false);
 }
 
+// ------------------------------------------------------------------------------------------
+// The work list ("items", round 4): lanes per bucket in proportion to its population.
+// A launch with few buckets, or with short ones, is a single round of waves whose duration is its LONGEST lane: with one lane per bucket
+// that is the largest population (n = 2^16 in 14-bit windows: mean 8, largest ~22), with K slices per bucket it is largest / K, and K is
+// the same for a bucket of 3 entries and one of 30.  Here every lane adds at most T entries: a bucket of cnt entries is served by
+// ni = ceil(cnt / T) lanes (at most ITEMS_NI_MAX; what a skewed bucket holds beyond that goes to the tail kernels as before), each taking
+// ceil(cnt / ni) of them.  No list is materialised: the buckets are already ordered by falling population (`order`, counting sort on
+// the key of sort_kernels.hpp), so all buckets of one population class are consecutive ranks and get the same ni -- the item index of
+// a lane, the rank of its bucket and its slice follow from two 1025-entry prefix tables over the classes (items before class k,
+// buckets before class k: k_items_plan, one workgroup), found by binary search.  Lanes of buckets that need only one lane write the
+// bucket itself; the others leave their sums in `items_out` and k_join_items adds the ni sums of every multi-lane bucket (the
+// multi-lane buckets are a prefix of the ranks), with the addition expanded inline: no private segment.
+// ------------------------------------------------------------------------------------------
+// largest k in [0, 1023] with tab[k] <= g, given tab[1024] > g (tab: non-decreasing exclusive prefix, 1025 entries)
+MSM_D uint32_t items_class_of(const uint32_t* __restrict__ tab, uint32_t g) {
+    uint32_t lo = 0, hi = ITEMS_CLASSES;
+#pragma unroll
+    for (int it = 0; it < 10; ++it) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab[mid] <= g) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+// (the tables: k_items_plan in sort_kernels.hpp -- itab[0 .. 1024]: items before class k, the total at [1024]; itab[1025 .. 2049]: buckets before class k)
+template <class F, int VARIANT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AccWaves<F>::value))) k_accumulate_items(
+    const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offset,
+    const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, const uint32_t* __restrict__ itab, uint32_t T, uint32_t osh,
+    uint8_t* __restrict__ buckets, uint8_t* __restrict__ items_out) {
+    constexpr uint32_t TL = UKind<F>::type::LANES, PER_WAVE = 64u / TL;
+    const uint32_t total = itab[ITEMS_CLASSES];
+    if (blockIdx.x * PER_WAVE >= total) return;   // (the grid is sized for the most items the entries could make: the whole wave leaves)
+    const uint32_t g = blockIdx.x * PER_WAVE + threadIdx.x / TL, sub = threadIdx.x % TL;
+    const bool live = g < total;
+    uint32_t from = 0, len = 0, b = 0, ni = 1;
+    if (live) {
+        const uint32_t k = items_class_of(itab, g), j = g - itab[k];
+        ni = items_ni(k, T, osh);
+        const uint32_t r = itab[ITEMS_CLASSES + 1u + k] + j / ni, s = j % ni;
+        b = order[r];
+        const uint32_t cnt = count[b], covered = min(cnt, ni * T), chunk = (covered + ni - 1u) / ni, first = min(s * chunk, covered);
+        from = offset[b] + first;
+        len = min(chunk, covered - first);
+    }
+    BU<F> acc;
+#if MSM_ACC_STAGED
+    if constexpr (TL == 1) {
+        __shared__ uint32_t tile[STAGE_WORDS];
+        acc = accumulate_span_staged<F>(bases, xbeta, sorted, from, len, tile);
+    } else
+#endif
+    {
+        acc = accumulate_span<F>(bases, xbeta, sorted, from, len);   // (both lanes of a pair hold the same from / len)
+    }
+    if (!live) return;
+    if (ni == 1) store16(buckets + ((size_t)b * TL + sub) * sizeof(BU<F>), acc);
+    else store16(items_out + ((size_t)g * TL + sub) * sizeof(BU<F>), acc);
+}
+// one (logical) lane per multi-lane bucket -- ranks [0, first rank of a one-lane class): the ni sums of the bucket, added with the
+// addition expanded inline; what the bucket holds beyond ni * T entries (skewed inputs only) is queued for the tail kernels
+template <class F>
+__global__ void __launch_bounds__(64) k_join_items(const uint32_t* __restrict__ count, const uint32_t* __restrict__ order, const uint32_t* __restrict__ itab, uint32_t T,
+                                                    uint32_t osh, const uint8_t* __restrict__ items_out, uint8_t* __restrict__ buckets, uint32_t seg, uint32_t seg_t,
+                                                    TailCtl* __restrict__ ctl, uint4* __restrict__ work, uint4* __restrict__ biglist) {
+    constexpr uint32_t TL = UKind<F>::type::LANES;
+    const uint32_t gt = blockIdx.x * 64u + threadIdx.x, r = gt / TL, sub = gt % TL;
+    const uint32_t* rtab = itab + ITEMS_CLASSES + 1u;
+    if (r >= rtab[ITEMS_CLASSES]) return;   // (both lanes of a pair leave together)
+    const uint32_t k = items_class_of(rtab, r), ni = items_ni(k, T, osh);
+    if (ni == 1) return;
+    const uint32_t g0 = itab[k] + (r - rtab[k]) * ni;
+    BU<F> acc = load16<BU<F>>(items_out + ((size_t)g0 * TL + sub) * sizeof(BU<F>));
+    for (uint32_t s = 1; s < ni; ++s) acc = BU<F>::add(acc, load16<BU<F>>(items_out + ((size_t)(g0 + s) * TL + sub) * sizeof(BU<F>)));
+    const uint32_t b = order[r], cnt = count[b], covered = min(cnt, ni * T);
+    store16(buckets + ((size_t)b * TL + sub) * sizeof(BU<F>), acc);
+    if (cnt > covered && sub == 0) {
+        const bool hot = cnt > HOT_FACTOR * seg;
+        queue_segments(ctl, work, biglist, b, cnt, covered, hot ? seg_t : seg, hot);
+    }
+}
+
 template <class F>
 __global__ void __launch_bounds__(256) k_accumulate_tail(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ xbeta, const uint32_t* __restrict__ sorted,
                                                           const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
@@ -613,6 +695,24 @@ void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const
     }
     k_join_slices<F><<<(uint32_t)(((uint64_t)nb * T + 63u) / 64u), 64, 0, st>>>(count, order, nb, k, slices, buckets, seg, (TailCtl*)ctl, (uint4*)work, (uint4*)biglist);
 }
+template <class F, int VARIANT>
+void launch_accumulate_items(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                             const uint32_t* order, const uint32_t* itab, uint32_t T, uint32_t osh, uint32_t max_items, uint8_t* buckets, uint8_t* items_out) {
+#if defined(MSM_U_CHAINED_MADS)
+    static_assert(VARIANT == 1, "this translation unit builds the chained variant");
+#else
+    static_assert(VARIANT == 0, "this translation unit builds the two-chain variant");
+#endif
+    constexpr uint32_t PER_WAVE = 64u / UKind<F>::type::LANES;
+    k_accumulate_items<F, VARIANT><<<(max_items + PER_WAVE - 1u) / PER_WAVE, 64, 0, st>>>(bases, xbeta, sorted, offset, count, order, itab, T, osh, buckets, items_out);
+}
+template <class F>
+void launch_join_items(hipStream_t st, const uint32_t* count, const uint32_t* order, const uint32_t* itab, uint32_t T, uint32_t osh, uint32_t max_multi,
+                       const uint8_t* items_out, uint8_t* buckets, uint32_t seg, uint32_t seg_t, void* ctl, void* work, void* biglist) {
+    constexpr uint32_t TL = UKind<F>::type::LANES;
+    k_join_items<F><<<(uint32_t)(((uint64_t)max_multi * TL + 63u) / 64u), 64, 0, st>>>(count, order, itab, T, osh, items_out, buckets, seg, seg_t, (TailCtl*)ctl, (uint4*)work,
+                                                                                    (uint4*)biglist);
+}
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
@@ -655,6 +755,12 @@ uint32_t lanes_per_point() {
                                                        const uint32_t*, uint32_t, uint8_t*, uint32_t);
 #define MSM_INSTANTIATE_JOIN(F)                                                                                                              \
     template void launch_join_slices<F>(hipStream_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t, const uint8_t*, uint8_t*, uint32_t, void*, void*, void*);
+#define MSM_INSTANTIATE_ITEMS(F, VARIANT)                                                                                                    \
+    template void launch_accumulate_items<F, VARIANT>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, \
+                                                      const uint32_t*, uint32_t, uint32_t, uint32_t, uint8_t*, uint8_t*);
+#define MSM_INSTANTIATE_JOIN_ITEMS(F)                                                                                                        \
+    template void launch_join_items<F>(hipStream_t, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, uint32_t, uint32_t, const uint8_t*, uint8_t*, uint32_t, \
+                                       uint32_t, void*, void*, void*);
 #define MSM_INSTANTIATE_TAIL(F)                                                                                                              \
     template void launch_accumulate_tail<F>(hipStream_t, const uint8_t*, const uint8_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint8_t*,    \
                                             uint32_t, void*, void*, void*, uint8_t*, uint32_t, bool);

@@ -663,21 +663,22 @@ int msm_amd_multiexp_dist_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* local_
     int my_rank = 0, world = 0;
     if (int rc = dist_group_alive(ctx, &my_rank, &world)) return rc;
     (void)my_rank;
-    uint32_t info[6];
-    if (!local_table || msm_amd_bases_info(local_table, info, nullptr)) {
-        msm_set_err(ctx, "multiexp_dist_prepared: no table");
+    int curve = 0, group = 0;
+    if (!local_table || !msm_bases_lookup(ctx, local_table, &curve, &group)) {
+        msm_set_err(ctx, "multiexp_dist_prepared: not a table of this context (or already released)");
         return MSM_AMD_EINVAL;
     }
-    int curve = 0, group = 0;
-    msm_bases_kind(local_table, &curve, &group);
     return dist_submit(ctx, curve, group, flags, nullptr, scalars_local, scalar_size, n_local, 0, 1, (uint32_t)world, 0, ticket, 0, std::string(), local_table);
 }
 int msm_amd_multiexp_dist_prepared(msm_amd_ctx* ctx, msm_amd_bases* local_table, uint32_t flags, const void* scalars_local, uint32_t scalar_size,
                                    uint32_t n_local, uint8_t* out) {
     uint64_t t = 0;
-    if (int rc = msm_amd_multiexp_dist_prepared_async(ctx, local_table, flags, scalars_local, scalar_size, n_local, &t)) return rc;
     int curve = 0, group = 0;
-    msm_bases_kind(local_table, &curve, &group);
+    if (!ctx || !local_table || !msm_bases_lookup(ctx, local_table, &curve, &group)) {
+        if (ctx) msm_set_err(ctx, "multiexp_dist_prepared: not a table of this context (or already released)");
+        return MSM_AMD_EINVAL;
+    }
+    if (int rc = msm_amd_multiexp_dist_prepared_async(ctx, local_table, flags, scalars_local, scalar_size, n_local, &t)) return rc;
     return msm_amd_dist_wait(ctx, curve, group, t, out);
 }
 

@@ -33,6 +33,12 @@ void launch_accumulate_slices(hipStream_t st, uint32_t k, const uint8_t* bases, 
 template <class F>
 void launch_join_slices(hipStream_t st, uint32_t k, const uint32_t* count, const uint32_t* order, uint32_t nb, const uint8_t* slices, uint8_t* buckets,
                         uint32_t seg, void* ctl, void* work, void* biglist);
+template <class F, int VARIANT>
+void launch_accumulate_items(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
+                             const uint32_t* order, const uint32_t* itab, uint32_t T, uint32_t osh, uint32_t max_items, uint8_t* buckets, uint8_t* items_out);
+template <class F>
+void launch_join_items(hipStream_t st, const uint32_t* count, const uint32_t* order, const uint32_t* itab, uint32_t T, uint32_t osh, uint32_t max_multi,
+                       const uint8_t* items_out, uint8_t* buckets, uint32_t seg, uint32_t seg_t, void* ctl, void* work, void* biglist);
 template <class F>
 void launch_accumulate_tail(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset,
                             const uint32_t* count, uint8_t* buckets, uint32_t seg, void* ctl, void* work, void* biglist, uint8_t* seg_out,
@@ -183,6 +189,7 @@ struct MsmCall {
     const uint8_t *d_bases = nullptr, *d_scalars = nullptr, *d_xbeta = nullptr;
     Geom g{};
     uint32_t nv = 0, nve = 0, NB = 0, nblk = 0, oblk = 0, w_split = 0, split = 0;
+    uint32_t items_T = 0, items_osh = 0;     // the accumulation's work list (bucket_kernels.hpp): entries per lane (0 = not used), population class step
     uint32_t *count = nullptr, *offset = nullptr, *order = nullptr, *bins = nullptr, *sorted = nullptr;
     uint8_t* buckets = nullptr;
 
@@ -417,6 +424,26 @@ int MsmCall<F>::plan() {
     split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
     w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
     split = w_split * g.half;                                               // first bucket of the second group
+    // The work list (k_accumulate_items, bucket_kernels.hpp): lanes per bucket in proportion to its population, every lane at most T
+    // entries.  For launches that do not fill the chip several times over anyway -- small n, the windows one rank of a sharded call
+    // owns -- where the duration of the single round of waves is its longest lane.  T brings the launch to ~320 k lanes (five waves per
+    // SIMD) and is at least 8 (a lane's bucket write and the join's full addition want some additions to amortise over); buckets
+    // whose mean needs more than ITEMS_NI_MAX / 2 lanes (a handful of very long buckets: small n in 8-bit windows) keep the sliced
+    // launch with its tree join.  Option "items": 0 = by this rule, 1 = wherever the mean allows, 2 = never.
+    items_T = items_osh = 0;
+    {
+        const uint64_t entries = (uint64_t)g.Wl * nve;
+        const uint32_t lanes_goal = KernelField<F>::chained_variant ? ctx->splitk_lanes : ctx->splitk_lanes / 3u;
+        const uint32_t mean = (nve + g.half - 1) / g.half;
+        uint32_t T = (uint32_t)std::max<uint64_t>(8, (entries + lanes_goal - 1) / lanes_goal);
+        if (ctx->items_t) T = ctx->items_t;
+        const bool fits = (mean + T - 1) / T <= ITEMS_NI_MAX / 2 && T <= 512;
+        const bool wanted = ctx->items_mode == 1 || (ctx->items_mode == 0 && NB < lanes_goal);
+        if (fits && wanted && !split_mode && !ctx->no_split2 && !ctx->splitk && !ctx->force_seg) {
+            items_T = T;
+            while (((uint64_t)(ITEMS_CLASSES - 1) << items_osh) < (uint64_t)ITEMS_NI_MAX * T) ++items_osh;   // every population the lanes cover lies inside a class
+        }
+    }
     return 0;
 }
 
@@ -579,8 +606,12 @@ do {                                    \
             k_big_scatter<uint32_t, 1024, BIG_CHUNK><<<bigs_grid, 1024, big_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, bcursor, sorted);
         }
     }
-    k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, bins);
-    k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, bins, bins + ORDER_KEYS, order);
+    k_order_hist<<<oblk, 1024, 0, st>>>(count, NB, split, items_osh, bins);
+    k_order_scatter<<<oblk, 1024, 0, st>>>(count, NB, split, items_osh, bins, bins + ORDER_KEYS, order);
+    if (items_T) {
+        if (int rc = ensure(ctx, sl->d_itab, (2 * (size_t)ITEMS_CLASSES + 2) * 4)) return rc;
+        k_items_plan<<<1, 1024, 0, st>>>(bins, items_T, items_osh, (uint32_t*)sl->d_itab.p);
+    }
     HIPCHK(ctx, hipEventRecord(sl->ev[4], st));
     return 0;
 }
@@ -667,7 +698,14 @@ int MsmCall<F>::accumulate() {
     if (int rc = ensure(ctx, sl->d_work, max_segs * 16)) return rc;
     if (int rc = ensure(ctx, sl->d_biglist, max_segs * 16)) return rc;
     if (int rc = ensure(ctx, sl->d_segout, max_segs * BSZ)) return rc;
-    if (k_first > 1 || k_second > 1)
+    // the work list: at most entries / T + buckets lanes.  Only the lanes of multi-lane buckets leave their sums in `slices`, and they
+    // come first: such a bucket holds more than T - 2^osh >= T / 2 entries (its population class reaches beyond T), so there are fewer than
+    // 2 x entries / T of them, with fewer than 3 x entries / T lanes
+    const uint32_t max_items = items_T ? (uint32_t)std::min<uint64_t>(all_entries / items_T + NB, 0xffffffc0ull) : 0u;
+    const uint32_t max_multi = items_T ? (uint32_t)std::min<uint64_t>(2 * (all_entries / items_T) + 1, NB) : 0u;
+    if (items_T) {
+        if (int rc = ensure(ctx, sl->d_slices, (size_t)std::min<uint64_t>(max_items, 3 * (all_entries / items_T) + 64) * BSZ)) return rc;
+    } else if (k_first > 1 || k_second > 1)
         if (int rc = ensure(ctx, sl->d_slices, std::max((size_t)split * k_first, (size_t)(NB - split) * k_second) * BSZ)) return rc;
     uint32_t tail_block = 256;
     while ((size_t)tail_block * BSZ > 64 * 1024 && tail_block > 64) tail_block /= 2;
@@ -676,6 +714,21 @@ int MsmCall<F>::accumulate() {
     // on every SIMD, the two-chain one otherwise
     auto accumulate = [&](const uint32_t* ord, uint32_t nbk, uint32_t k) -> int {
         HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+        if (items_T) {   // (one group only: plan() keeps the work list off when the call is split)
+            const uint32_t* itab = (const uint32_t*)sl->d_itab.p;
+            uint8_t* items_out = (uint8_t*)sl->d_slices.p;
+            if constexpr (KernelField<F>::chained_variant) {
+                const bool chained = ctx->acc_variant ? ctx->acc_variant == 2 : all_entries / items_T >= 2u * 1024u * 64u;
+                if (chained) launch_accumulate_items<FK, 1>(st, d_bases, d_xbeta, sorted, offset, count, ord, itab, items_T, items_osh, max_items, buckets, items_out);
+                else launch_accumulate_items<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, itab, items_T, items_osh, max_items, buckets, items_out);
+            } else {
+                launch_accumulate_items<FK, 0>(st, d_bases, d_xbeta, sorted, offset, count, ord, itab, items_T, items_osh, max_items, buckets, items_out);
+            }
+            launch_join_items<FK>(st, count, ord, itab, items_T, items_osh, max_multi, items_out, buckets, seg, seg_t, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p);
+            launch_accumulate_tail<FK>(st, d_bases, d_xbeta, sorted, offset, count, buckets, seg, sl->d_tailctl.p, sl->d_work.p, sl->d_biglist.p,
+                                       (uint8_t*)sl->d_segout.p, tail_block, tail_expected);
+            return 0;
+        }
         const uint32_t seg_lane = (seg + k - 1) / k;
         if constexpr (KernelField<F>::chained_variant) {
             const bool chained = ctx->acc_variant ? ctx->acc_variant == 2 : (uint64_t)nbk * k >= 2u * 1024u * 64u;
@@ -896,6 +949,11 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
     if (!ctx) return MSM_AMD_EINVAL;
     std::unique_lock<std::mutex> lk(ctx->mu);
     if (int rc = check_args(ctx, a)) return rc;
+    // (a prepared table is checked and counted in under this lock, the one msm_amd_release_bases frees it under)
+    if (a.prepared && std::find(ctx->prepared_handles.begin(), ctx->prepared_handles.end(), a.prepared) == ctx->prepared_handles.end()) {
+        msm_set_err(ctx, "multiexp_prepared: these bases have been released");
+        return MSM_AMD_EINVAL;
+    }
     Slot* sl = nullptr;
     for (;;) {
         for (uint32_t k = 0; k < ctx->nslots; ++k) {   // tickets may be collected in any order: take any free slot
@@ -1280,6 +1338,8 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->splitk = value;
         return 0;
     }
+    if (!strcmp(name, "items")) { ctx->items_mode = value > 2 ? 0 : (int)value; return 0; }   // the accumulation's work list: 0 = where a launch is short of filling the chip, 1 = wherever the populations allow, 2 = never
+    if (!strcmp(name, "items_t")) { ctx->items_t = value; return 0; }                         // experiments: entries per lane of the work list (0 = chosen per launch)
     if (!strcmp(name, "hot")) { ctx->no_hot = value == 0; return 0; }   // 0 = hot buckets take the ordinary segment path (before / after measurements)
     if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return 0; }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
@@ -1356,10 +1416,14 @@ int msm_amd_multiexp_shard(msm_amd_ctx* ctx, int curve, int group, uint32_t flag
 }
 
 // ---- prepared bases: the table is built in prepared.hip; the calls on a handle are ordinary submissions ---------------------------
-static int prepared_args(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, RunArgs* a) {
+// The handle is looked up among the context's registered tables BEFORE it is dereferenced, under the lock msm_amd_release_bases takes:
+// a handle of another context, or one already released (by this or another thread), is refused instead of read.  submit() repeats the
+// look-up in the critical section that counts the call in, so a release between here and there is caught as well.
+static int prepared_args(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, RunArgs* a, int* curve, int* group) {
     if (!ctx || !h) return MSM_AMD_EINVAL;
-    if (h->ctx != ctx) {
-        msm_set_err(ctx, "multiexp_prepared: the bases were prepared on another context");
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (std::find(ctx->prepared_handles.begin(), ctx->prepared_handles.end(), h) == ctx->prepared_handles.end()) {
+        msm_set_err(ctx, "multiexp_prepared: not bases of this context (prepared on another context, or already released)");
         return MSM_AMD_EINVAL;
     }
     if (n > h->n) {
@@ -1371,23 +1435,27 @@ static int prepared_args(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, con
         return MSM_AMD_EINVAL;
     }
     *a = RunArgs{h->table, scalars, scalar_size, n, flags, 0, scalar_size * 8, 0, 1, false, h};
+    *curve = h->curve;
+    *group = h->group;
     return 0;
 }
 // R = sum_{i < n} scalar_i * P_i over the first n prepared points
 int msm_amd_multiexp_prepared(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n, uint8_t* out) {
     RunArgs a;
-    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a)) return rc;
+    int curve = 0, group = 0;
+    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a, &curve, &group)) return rc;
     if (!out) return MSM_AMD_EINVAL;
     uint64_t t = 0;
-    if (int rc = submit(ctx, h->curve, h->group, a, &t, true)) return rc;
+    if (int rc = submit(ctx, curve, group, a, &t, true)) return rc;
     return finish_ticket(ctx, t, out);
 }
 int msm_amd_multiexp_prepared_async(msm_amd_ctx* ctx, msm_amd_bases* h, uint32_t flags, const void* scalars, uint32_t scalar_size, uint32_t n,
                                     uint64_t* ticket) {
     RunArgs a;
+    int curve = 0, group = 0;
     if (!ticket) return MSM_AMD_EINVAL;
-    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a)) return rc;
-    return submit(ctx, h->curve, h->group, a, ticket);
+    if (int rc = prepared_args(ctx, h, flags, scalars, scalar_size, n, &a, &curve, &group)) return rc;
+    return submit(ctx, curve, group, a, ticket);
 }
 
 #define BY_FIELD(curve, group, CALL)                                                         \

@@ -46,6 +46,15 @@ MSM_D void store16(void* p, const T& t) {
 constexpr uint32_t HOT_FACTOR = 32, HOT_GROUPS = 32, HOT_MAX = 1024, HOT_MIN_SEGS = 4096;   // (fewer segments than that: one workgroup folds them -- 32 trees over a few hundred values cost more than they save)
 constexpr size_t HOT_LIST_OFFSET = 16, HOT_PART_OFFSET = HOT_LIST_OFFSET + (size_t)HOT_MAX * 4;   // bytes from `ctl`
 
+// The work list of the accumulation (bucket_kernels.hpp k_accumulate_items): lanes per bucket by population class.
+constexpr uint32_t ITEMS_NI_MAX = 8, ITEMS_CLASSES = 1024;   // (= ORDER_BINS of sort_kernels.hpp, static_asserted there)
+// lanes per bucket of population class `key` (key = 1023 - min(cnt >> osh, 1023): sort_kernels.hpp order_key)
+MSM_HD uint32_t items_ni(uint32_t key, uint32_t T, uint32_t osh) {
+    const uint32_t pop_hi = (((ITEMS_CLASSES - 1u) - key + 1u) << osh) - 1u;   // the largest population of the class (class 0 is open-ended: its lanes cover ni * T)
+    const uint32_t ni = (pop_hi + T - 1u) / T;
+    return ni < 1u ? 1u : (ni > ITEMS_NI_MAX ? ITEMS_NI_MAX : ni);
+}
+
 constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 8 coarse + 12 fine bits of bucket index (the sort's two levels, sort_kernels.hpp)
 
 // Window geometry shared by host and kernels.

@@ -57,6 +57,7 @@ using namespace msm;
 // two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
 // the sort + accumulation of the next call (throughput-bound, stream A).
 struct Slot {
+    DevBuf d_itab;    // the work list's two class prefix tables (k_items_plan)
     DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout, d_slices;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
@@ -80,7 +81,7 @@ struct Slot {
     msm_amd_bases* prepared = nullptr;   // the call runs on a prepared table (released from in_flight when collected)
     DevBuf d_flags;                      // word 0: a scalar had bits beyond the windows of the prepared table
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
-    DevBuf* bufs[25] = {&d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+    DevBuf* bufs[26] = {&d_itab, &d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
 
@@ -178,6 +179,8 @@ struct msm_amd_ctx {
     int zero_copy = 1;      // option "zero_copy" (default 1): the reduction writes its partials and the tail words straight into the pinned host buffer -- no copy back (15 us of every call); 0 = device buffer + one copy
     int no_split2 = 0;      // option "split2" = 0: one lane per bucket always (switches k_accumulate_slices off)
     uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0, chunk_mode = 0;
+    int items_mode = 0;     // option "items": the accumulation's work list (0 = by launch size, 1 = wherever the populations allow, 2 = never)
+    uint32_t items_t = 0;   // option "items_t": entries per lane of the work list (0 = chosen per launch)
     uint32_t splitk = 0;    // option "splitk": lanes per bucket of the G1 accumulation, 0 = chosen per launch, 1..MAX_SLICES forced
     uint32_t splitk_lanes = 5u * 1024u * 64u;   // option "splitk_lanes": the lane count a launch with few buckets is brought to (five waves for each of 1024 SIMDs)
     uint32_t max_slice = 1u << 26;   // synchronous calls with more points are cut into slices of this many (option "slice")
@@ -190,6 +193,16 @@ struct msm_amd_ctx {
     float timings[8] = {};
     uint32_t geometry[6] = {};
 };
+
+// curve and group of a prepared table, looked up among the context's registered tables before it is dereferenced (false: not a table
+// of this context, or released)
+inline bool msm_bases_lookup(msm_amd_ctx* ctx, const msm_amd_bases* h, int* curve, int* group) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (std::find(ctx->prepared_handles.begin(), ctx->prepared_handles.end(), h) == ctx->prepared_handles.end()) return false;
+    *curve = h->curve;
+    *group = h->group;
+    return true;
+}
 
 // Error text of a context.  Written by whichever thread fails (several may use one context: the libuv workers of the Node addon),
 // so it is guarded by its own small lock, and msm_amd_last_error hands out a per-thread copy.

@@ -199,17 +199,20 @@ int msm_amd_prepare_bases(msm_amd_ctx* ctx, int curve, int group, uint32_t flags
 int msm_amd_release_bases(msm_amd_ctx* ctx, msm_amd_bases* h) {
     if (!ctx) return MSM_AMD_EINVAL;
     if (!h) return 0;
-    if (h->ctx != ctx) {
-        msm_set_err(ctx, "release_bases: the handle belongs to another context");
-        return MSM_AMD_EINVAL;
-    }
-    if (h->in_flight.load() > 0) {
-        msm_set_err(ctx, "release_bases: calls on these bases are still in flight (wait for their tickets first)");
-        return MSM_AMD_EINVAL;
-    }
     {
+        // One critical section with submit() (engine.hip), which counts a call in under the same lock after checking that its table is
+        // still registered: a table is either released or gets a new call, never both (a thread sharing the table could otherwise
+        // submit between the in-flight check and the free, and its kernels would gather from freed memory).
         std::lock_guard<std::mutex> lk(ctx->mu);
         auto& v = ctx->prepared_handles;
+        if (std::find(v.begin(), v.end(), h) == v.end()) {   // (also: a handle of another context, or one released before -- never dereferenced)
+            msm_set_err(ctx, "release_bases: not a handle of this context (another context's, or already released)");
+            return MSM_AMD_EINVAL;
+        }
+        if (h->in_flight.load() > 0) {
+            msm_set_err(ctx, "release_bases: calls on these bases are still in flight (wait for their tickets first)");
+            return MSM_AMD_EINVAL;
+        }
         v.erase(std::remove(v.begin(), v.end(), h), v.end());
     }
     (void)hipSetDevice(ctx->device);

@@ -444,8 +444,11 @@ constexpr int ORDER_BINS = 1024;
 // [buckets of the first window group by falling population][buckets of the second group by falling population],
 // which lets the engine accumulate and reduce the two groups in two overlapping waves (see submit_msm).
 constexpr int ORDER_KEYS = 2 * ORDER_BINS;
-MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split) {
-    return (b >= split ? (uint32_t)ORDER_BINS : 0u) + ((ORDER_BINS - 1) - min(cnt, (uint32_t)(ORDER_BINS - 1)));   // big buckets first
+static_assert(ORDER_BINS == (int)ITEMS_CLASSES, "the work list's population classes are the ordering keys");
+// osh: populations are classed in steps of 2^osh (0 except where buckets hold more than ~1000 entries AND the accumulation runs its
+// work list, which needs every population it serves inside a class: engine.hip)
+MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split, uint32_t osh) {
+    return (b >= split ? (uint32_t)ORDER_BINS : 0u) + ((ORDER_BINS - 1) - min(cnt >> osh, (uint32_t)(ORDER_BINS - 1)));   // big buckets first
 }
 // ------------------------------------------------------------------------------------------
 // fine sort of one (window, coarse bin) span: bucket count / offset tables and the index lists grouped by bucket
@@ -752,12 +755,12 @@ __global__ void __launch_bounds__(BIGS_BLOCK) k_big_scatter(const E* __restrict_
 // ------------------------------------------------------------------------------------------
 // obins[k] += number of buckets with ordering key k.  (Tallying the keys inside the fine-sort kernels, which hold the populations in
 // LDS, was tried: the extra barriers and the 2048-word scratch cost k_fine_small more than this 8-us pass saves.)
-__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t* __restrict__ obins) {
+__global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t osh, uint32_t* __restrict__ obins) {
     __shared__ uint32_t h[ORDER_KEYS];
     h[threadIdx.x] = 0;
     h[threadIdx.x + ORDER_BINS] = 0;
     __syncthreads();
-    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) atomicAdd(&h[order_key(b, count[b], split)], 1u);
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nb; b += gridDim.x * blockDim.x) atomicAdd(&h[order_key(b, count[b], split, osh)], 1u);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&obins[threadIdx.x], h[threadIdx.x]);
     if (h[threadIdx.x + ORDER_BINS]) atomicAdd(&obins[threadIdx.x + ORDER_BINS], h[threadIdx.x + ORDER_BINS]);
@@ -765,7 +768,7 @@ __global__ void __launch_bounds__(1024) k_order_hist(const uint32_t* __restrict_
 // order[]: the buckets by falling population.  obins[k] = number of buckets with key k (k_order_hist); every
 // workgroup scans those 2048 counters itself (an exclusive prefix: where each key's buckets start), counts the keys of its own span of
 // buckets in LDS, reserves their places with one atomic per key on ocur[k], and writes its buckets there.
-__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, const uint32_t* __restrict__ obins,
+__global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restrict__ count, uint32_t nb, uint32_t split, uint32_t osh, const uint32_t* __restrict__ obins,
                                                          uint32_t* __restrict__ ocur, uint32_t* __restrict__ order) {
     __shared__ uint32_t h[ORDER_KEYS];
     __shared__ uint32_t basep[ORDER_KEYS];
@@ -788,7 +791,7 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restri
     // each workgroup owns a contiguous span of buckets
     uint32_t per = (nb + gridDim.x - 1) / gridDim.x;
     uint32_t lo = blockIdx.x * per, hi = min(nb, lo + per);
-    for (uint32_t bk = lo + t; bk < hi; bk += blockDim.x) atomicAdd(&h[order_key(bk, count[bk], split)], 1u);
+    for (uint32_t bk = lo + t; bk < hi; bk += blockDim.x) atomicAdd(&h[order_key(bk, count[bk], split, osh)], 1u);
     __syncthreads();
     basep[2 * t] = excl + (h[2 * t] ? atomicAdd(&ocur[2 * t], h[2 * t]) : 0u);
     basep[2 * t + 1] = excl + a + (h[2 * t + 1] ? atomicAdd(&ocur[2 * t + 1], h[2 * t + 1]) : 0u);
@@ -797,10 +800,42 @@ __global__ void __launch_bounds__(1024) k_order_scatter(const uint32_t* __restri
     h[t + ORDER_BINS] = 0;
     __syncthreads();
     for (uint32_t bk = lo + t; bk < hi; bk += blockDim.x) {
-        uint32_t key = order_key(bk, count[bk], split);
+        uint32_t key = order_key(bk, count[bk], split, osh);
         uint32_t p = basep[key] + atomicAdd(&h[key], 1u);
         order[p] = bk;
     }
 }
 
+// The two prefix tables of the accumulation's work list (bucket_kernels.hpp), from the class populations the ordering pass has counted
+// (first window group only: the work list is not used when a lone call is split in two groups).
+// itab[0 .. 1024]: items before class k (the total at [1024]); itab[1025 .. 2049]: buckets before class k (all buckets at [2049])
+__global__ void __launch_bounds__(1024) k_items_plan(const uint32_t* __restrict__ obins, uint32_t T, uint32_t osh, uint32_t* __restrict__ itab) {
+    __shared__ uint32_t wsum_i[16], wsum_b[16];
+    const uint32_t t = threadIdx.x, nbk = obins[t], nit = nbk * items_ni(t, T, osh);
+    uint32_t inc_i = nit, inc_b = nbk;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t oi = __shfl_up(inc_i, d, 64), ob = __shfl_up(inc_b, d, 64);
+        if ((int)(t & 63u) >= d) {
+            inc_i += oi;
+            inc_b += ob;
+        }
+    }
+    if ((t & 63u) == 63u) {
+        wsum_i[t >> 6] = inc_i;
+        wsum_b[t >> 6] = inc_b;
+    }
+    __syncthreads();
+    uint32_t ex_i = inc_i - nit, ex_b = inc_b - nbk;
+    for (uint32_t q = 0; q < (t >> 6); ++q) {
+        ex_i += wsum_i[q];
+        ex_b += wsum_b[q];
+    }
+    itab[t] = ex_i;
+    itab[ITEMS_CLASSES + 1u + t] = ex_b;
+    if (t == ITEMS_CLASSES - 1u) {
+        itab[ITEMS_CLASSES] = ex_i + nit;
+        itab[2u * ITEMS_CLASSES + 1u] = ex_b + nbk;
+    }
+}
 }  // namespace msm
