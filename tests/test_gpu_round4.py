@@ -6,7 +6,11 @@
   * a prepared table released while another thread submits on it, released twice, used after release.
 Reference semantics under test: wasmcurves/src/build_multiexp.js:186-233 (every (scalar, point) pair lands in exactly one bucket of
 every window) -- the work list only changes which lane adds which entries."""
+import json
+import os
 import random
+import subprocess
+import sys
 import threading
 
 import pytest
@@ -175,3 +179,21 @@ def test_release_of_a_prepared_table_is_atomic_with_submissions(orc):
         assert C.g1m_multiexpAffine(bases, scalars, 32, n) == exp        # the context is fine
     finally:
         eng.close()
+
+
+def test_a_nearly_full_device_gives_enomem_or_the_right_bytes():
+    """In a freshly started child process (tests/oom_worker.py): a context is created, the device is filled to ~200 MB free and then to
+    ~24 MB free, and G2 and G1 calls with queued segments -- the tail-combine kernels doing real work for the first time in the process --
+    are issued at both levels, plus the entry points whose kernels need more scratch than the context reserved.  Before round 4 the
+    HSA runtime ABORTED the process there (a queue's scratch could not be allocated at the dispatch).  Now the MSM path's kernels carry
+    no private segment beyond spills, their scratch is reserved by msm_amd_create, and the other entry points ask before they launch:
+    every call returns the right bytes or MSM_AMD_ENOMEM, and the child exits 0."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "oom_worker.py")], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, f"the child died ({p.returncode})\nstdout:\n{p.stdout[-3000:]}\nstderr:\n{p.stderr[-3000:]}"
+    res = json.loads(p.stdout.strip().splitlines()[-1])
+    log = os.path.join(root, "gpurun_out")
+    if os.path.isdir(log):
+        with open(os.path.join(log, "r04_oom_child.txt"), "w") as f:
+            f.write("\n".join(res["notes"]) + "\n")
+    assert res["ok"], res

@@ -9,6 +9,13 @@ pair) appears inside a callee.  The build therefore fails when
   * a non-kernel function contains an s_setpc_b64 through anything but the return address s[30:31] (a relaxed long branch),
 so that the next inlining change cannot silently bring the hang back.  Kernels are exempt (500-KiB kernels run fine).
 
+Round 4, a third rule: the PRIVATE SEGMENT of the MSM path's kernels.  The HSA runtime gives a hardware queue 64 x 8192 x (bytes of
+private segment per lane) of scratch when a kernel that needs it is dispatched, and aborts the process when that allocation fails on
+a nearly full device.  msm_amd_create reserves MSM_SCRATCH_RESERVE (csrc/engine_ctx.hpp) bytes per lane on every stream while failure
+can still be reported; every kernel that an MSM call may launch must stay within that -- the build fails when one of them does not.
+Kernels of the other entry points (group FFTs, batch conversions, batchApplyKey, the table build, point generation) are exempt BY NAME:
+they call out-of-line point arithmetic, and their launch sites ask msm_scratch_guard first.
+
 Usage: check_code_objects.py path/to/lib.so [--limit BYTES] [--list] [--sources csrc_dir]"""
 import os
 import re
@@ -66,6 +73,41 @@ def inspect(elf_bytes):
         os.unlink(tmp)
 
 
+GUARDED_AT_RUNTIME = ("k_fft_", "k_g_fft_", "k_fr_fft", "k_batch_", "k_fr_batch", "k_gen_points", "k_table_next", "k_glv_preprocess")
+
+
+def private_segments(elf_bytes):
+    """[(kernel name, private segment bytes per lane)] from the code object's metadata notes"""
+    with tempfile.NamedTemporaryFile(suffix=".elf", delete=False) as f:
+        f.write(elf_bytes)
+        tmp = f.name
+    try:
+        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", tmp], capture_output=True, text=True, check=True).stdout
+    finally:
+        os.unlink(tmp)
+    out, name, priv = [], None, None
+    for ln in notes.splitlines():
+        m = re.match(r"\s+-?\s*\.(\w+):\s+(.*)$", ln)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip()
+        if k == "name" and name is None and v.startswith("_Z") or (k == "name" and name is None and v.startswith("k_")):
+            name = v
+        elif k == "private_segment_fixed_size":
+            priv = int(v)
+        elif k == "wavefront_size":      # (the last key of a kernel's record)
+            if name is not None and priv is not None:
+                out.append((name, priv))
+            name, priv = None, None
+    return out
+
+
+def scratch_reserve(src_dir):
+    text = open(os.path.join(src_dir, "engine_ctx.hpp")).read()
+    m = re.search(r"MSM_SCRATCH_RESERVE\s*=\s*(\d+)", text)
+    return int(m.group(1)) if m else None
+
+
 def byvalue_points(src_dir):
     """Source scan: an out-of-line (__noinline__) device function must not take a point (XYZZ / XYZZU / Jacobian / Affine struct: up to
     448 bytes) BY VALUE -- two 384-byte by-value operands arrived corrupted in the callee.  Field-element operands
@@ -110,7 +152,27 @@ def main(argv):
     print(f"check_code_objects: {len(objs)} code objects, {len(rows) - len(nk)} kernels (largest {max([r[0] for r in rows if r[1]] or [0])} B), "
           f"{len(nk)} device functions (largest {max([r[0] for r in nk] or [0])} B, limit {limit} B)")
     if "--sources" in argv:
-        bad += byvalue_points(argv[argv.index("--sources") + 1])
+        src = argv[argv.index("--sources") + 1]
+        bad += byvalue_points(src)
+        reserve = scratch_reserve(src)
+        if reserve is None:
+            bad.append("MSM_SCRATCH_RESERVE not found in engine_ctx.hpp")
+        else:
+            worst, reserve_kernel = (0, ""), None
+            for triple, blob in objs:
+                for name, priv in private_segments(blob):
+                    demangled = name
+                    if "k_scratch_reserve" in name:      # the kernel msm_amd_create reserves the scratch WITH: at least the reserve
+                        reserve_kernel = priv
+                        continue
+                    if any(("3msm%d%s" % (len(pfx) + k, pfx)) in name or name.startswith(pfx) for pfx in GUARDED_AT_RUNTIME for k in range(0, 24)):
+                        continue
+                    worst = max(worst, (priv, demangled))
+                    if priv > reserve:
+                        bad.append(f"kernel of the MSM path with {priv} bytes of private segment per lane (> MSM_SCRATCH_RESERVE = {reserve}): {name}")
+            if reserve_kernel is None or reserve_kernel < reserve:
+                bad.append(f"k_scratch_reserve carries {reserve_kernel} bytes of private segment, less than MSM_SCRATCH_RESERVE = {reserve}")
+            print(f"check_code_objects: largest private segment among the MSM path's kernels: {worst[0]} B per lane (reserved at create: {reserve_kernel} B >= {reserve})")
     for b in bad:
         print("check_code_objects: FAIL:", b, file=sys.stderr)
     return 1 if bad else 0

@@ -178,6 +178,15 @@ struct ReduceInline {
     static constexpr bool value = InlineAdds<F>::value;
 #endif
 };
+// The tail and join kernels (k_join_slices[_tree], k_combine_tail[_lanes]) add with the addition EXPANDED INLINE as well (round 4).  Called
+// out of line, the operands of an addition live in the caller's private segment (three points: 450-1030 bytes per lane), and the HSA
+// runtime sizes a queue's scratch for the whole chip -- bytes per lane x 64 lanes x 8192 wave slots: 0.5 GB per hardware queue for
+// BLS12-381 G2, allocated at the first dispatch and kept (tools/microbench/scratch_dispatch.hip, profiles/r04_scratch_dispatch.txt);
+// when that allocation fails on a nearly full device the runtime aborts the process.  Inline, these kernels need no scratch at all.
+template <class F>
+MSM_D BU<F> tadd(const BU<F>& a, const BU<F>& b) {
+    return BU<F>::add(a, b);
+}
 // Occupancy target of the accumulation (waves per SIMD): 3 for G1 -- the kernel needs 165 VGPRs, three waves keep the
 // v_mad_u64_u32 pipe fed through the point loads; the Fp2 kernels need all 512 registers of a SIMD lane pair.
 #ifndef MSM_ACC_WAVES
@@ -283,7 +292,7 @@ __global__ void __launch_bounds__(64) k_join_slices(const uint32_t* __restrict__
     const uint32_t gt = blockIdx.x * 64u + threadIdx.x, r = gt / T, sub = gt % T;
     if (r >= nb) return;   // (both lanes of a pair leave together)
     BU<F> acc = load16<BU<F>>(slices + ((size_t)r * T + sub) * sizeof(BU<F>));
-    for (uint32_t s = 1; s < K; ++s) acc = BU<F>::add_ni(acc, load16<BU<F>>(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>)));
+    for (uint32_t s = 1; s < K; ++s) acc = tadd<F>(acc, load16<BU<F>>(slices + (((size_t)s * nb + r) * T + sub) * sizeof(BU<F>)));
     const uint32_t b = order[r], cnt = count[b];
     store16(buckets + ((size_t)b * T + sub) * sizeof(BU<F>), acc);
     if (cnt > K * seg && sub == 0) queue_segments(ctl, work, biglist, b, cnt, K * seg, seg, false);
@@ -305,7 +314,7 @@ __global__ void __launch_bounds__(256) k_join_slices_tree(const uint32_t* __rest
     for (uint32_t h = K >> 1; h >= 1; h >>= 1) {
         if (s >= h && s < 2 * h) sh[(s * B + rb) * T + sub] = acc;
         __syncthreads();
-        if (s < h) acc = BU<F>::add_ni(acc, sh[((s + h) * B + rb) * T + sub]);   // (s is the same for both lanes of a pair)
+        if (s < h) acc = tadd<F>(acc, sh[((s + h) * B + rb) * T + sub]);   // (s is the same for both lanes of a pair)
         __syncthreads();
     }
     if (s != 0 || !live) return;
@@ -422,51 +431,50 @@ __global__ void __launch_bounds__(256) k_combine_tail(const TailCtl* __restrict_
     BU<F>* sh = reinterpret_cast<BU<F>*>(smem);
     constexpr uint32_t T = UKind<F>::type::LANES;
     const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, nlt = blockDim.x / T;   // logical lane, component, logical lanes
-    const uint32_t nbig = ctl->nbig;
-    for (uint32_t bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
-        uint4 d = biglist[bi];   // bucket, first segment, number of segments, hot slot + 1
-        if (d.z <= TAIL_LANE_SEGS || d.w != 0) continue;   // (uniform over the workgroup; hot buckets: below)
-        BU<F> loc = BU<F>::inf();
-        for (uint32_t j = lt; j < d.z; j += nlt)
-            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
-        sh[threadIdx.x] = loc;
-        __syncthreads();
-        for (uint32_t s = nlt / 2; s > 0; s >>= 1) {
-            if (lt < s) {
-                BU<F> a = sh[threadIdx.x];
-                BU<F> bb = sh[threadIdx.x + s * T];
-                sh[threadIdx.x] = BU<F>::add_ni(a, bb);
-            }
-            __syncthreads();
-        }
-        if (lt == 0) {
-            BU<F> cur = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
-            store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), BU<F>::add_ni(cur, sh[threadIdx.x]));
-        }
-        __syncthreads();
-    }
-    // hot buckets, first fold: workgroup item (slot, g) sums the segments g * nlt + lt, + HOT_GROUPS * nlt, ... of hot bucket `slot` and
-    // leaves ONE partial sum; k_combine_tail_lanes (the next launch) folds the HOT_GROUPS partials of every hot bucket
-    const uint32_t nhot = min(ctl->nhot, HOT_MAX);
+    const uint32_t nbig = ctl->nbig, nhot = min(ctl->nhot, HOT_MAX);
     uint8_t* part = hot_part(ctl);
-    for (uint32_t it = blockIdx.x; it < nhot * HOT_GROUPS; it += gridDim.x) {
-        const uint32_t slot = it / HOT_GROUPS, g = it % HOT_GROUPS;
-        const uint4 d = biglist[hot_list(ctl)[slot]];
-        BU<F> loc = BU<F>::inf();
-        for (uint32_t j = g * nlt + lt; j < d.z; j += HOT_GROUPS * nlt)
-            loc = BU<F>::add_ni(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
-        sh[threadIdx.x] = loc;
-        __syncthreads();
-        for (uint32_t s = nlt / 2; s > 0; s >>= 1) {
-            if (lt < s) {
-                BU<F> a = sh[threadIdx.x];
-                BU<F> bb = sh[threadIdx.x + s * T];
-                sh[threadIdx.x] = BU<F>::add_ni(a, bb);
+    // Two kinds of work unit share ONE body (three inlined additions instead of six):
+    //   phase 0: an ordinary long bucket -- its segments summed by the whole workgroup and added to the bucket;
+    //   phase 1: hot buckets, first fold -- unit (slot, g) sums the segments g * nlt + lt, + HOT_GROUPS * nlt, ... of hot bucket `slot` and
+    //            leaves ONE partial sum; k_combine_tail_lanes (the next launch) folds the HOT_GROUPS partials of every hot bucket.
+    for (uint32_t phase = 0; phase < 2; ++phase) {
+        const uint32_t nunits = phase == 0 ? nbig : nhot * HOT_GROUPS;
+        for (uint32_t unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+            uint4 d;   // bucket, first segment, number of segments, hot slot + 1
+            uint32_t j0, jstep;
+            uint8_t* dst;
+            if (phase == 0) {
+                d = biglist[unit];
+                if (d.z <= TAIL_LANE_SEGS || d.w != 0) continue;   // (uniform over the workgroup; few segments: k_combine_tail_lanes; hot: phase 1)
+                j0 = lt;
+                jstep = nlt;
+                dst = buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>);
+            } else {
+                const uint32_t slot = unit / HOT_GROUPS, g = unit % HOT_GROUPS;
+                d = biglist[hot_list(ctl)[slot]];
+                j0 = g * nlt + lt;
+                jstep = HOT_GROUPS * nlt;
+                dst = part + ((size_t)unit * T + sub) * sizeof(BU<F>);
+            }
+            BU<F> loc = BU<F>::inf();
+            for (uint32_t j = j0; j < d.z; j += jstep) loc = tadd<F>(loc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
+            sh[threadIdx.x] = loc;
+            __syncthreads();
+            for (uint32_t s = nlt / 2; s > 0; s >>= 1) {
+                if (lt < s) {
+                    BU<F> a = sh[threadIdx.x];
+                    BU<F> bb = sh[threadIdx.x + s * T];
+                    sh[threadIdx.x] = tadd<F>(a, bb);
+                }
+                __syncthreads();
+            }
+            if (lt == 0) {
+                BU<F> r = sh[threadIdx.x];
+                if (phase == 0) r = tadd<F>(load16<BU<F>>(dst), r);
+                store16(dst, r);
             }
             __syncthreads();
         }
-        if (lt == 0) store16(part + ((size_t)it * T + sub) * sizeof(BU<F>), sh[threadIdx.x]);
-        __syncthreads();
     }
 }
 template <class F>
@@ -478,31 +486,37 @@ __global__ void __launch_bounds__(64) k_combine_tail_lanes(const TailCtl* __rest
         uint4 d = biglist[bi];
         if (d.z > TAIL_LANE_SEGS) continue;
         BU<F> acc = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
-        for (uint32_t j = 0; j < d.z; ++j) acc = BU<F>::add_ni(acc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
+        for (uint32_t j = 0; j < d.z; ++j) acc = tadd<F>(acc, load16<BU<F>>(seg_out + ((size_t)(d.y + j) * T + sub) * sizeof(BU<F>)));
         store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), acc);
     }
-    // hot buckets, second fold: the HOT_GROUPS partial sums that k_combine_tail (the previous launch) left per hot bucket, by one wave
+    // hot buckets, second fold: the HOT_GROUPS partial sums that k_combine_tail (the previous launch) left per hot bucket, by one wave;
+    // the bucket's own sum joins the tree as one more leaf (lane HOT_GROUPS), so that the fold is ONE inlined addition
     __shared__ __attribute__((aligned(16))) BU<F> shh[64];
     constexpr uint32_t NLT = 64u / T;   // logical lanes of this 64-thread workgroup
-    static_assert(HOT_GROUPS <= NLT, "one logical lane per partial sum");
+    static_assert(HOT_GROUPS < NLT || T == 2, "one logical lane per partial sum and one for the bucket");
     const uint32_t nhot = min(ctl->nhot, HOT_MAX), lt = threadIdx.x / T;
     const uint8_t* part = hot_part(ctl);
     for (uint32_t slot = blockIdx.x; slot < nhot; slot += gridDim.x) {
         const uint4 d = biglist[hot_list(ctl)[slot]];
-        shh[threadIdx.x] = lt < HOT_GROUPS ? load16<BU<F>>(part + (((size_t)slot * HOT_GROUPS + lt) * T + sub) * sizeof(BU<F>)) : BU<F>::inf();
+        uint8_t* dst = buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>);
+        if constexpr (HOT_GROUPS < NLT) {
+            shh[threadIdx.x] = lt < HOT_GROUPS ? load16<BU<F>>(part + (((size_t)slot * HOT_GROUPS + lt) * T + sub) * sizeof(BU<F>))
+                                               : (lt == HOT_GROUPS ? load16<BU<F>>(dst) : BU<F>::inf());
+        } else {   // (a point on a lane pair: 32 logical lanes hold the 32 partials; the bucket's own sum is added to lane 0's leaf below)
+            shh[threadIdx.x] = load16<BU<F>>(part + (((size_t)slot * HOT_GROUPS + lt) * T + sub) * sizeof(BU<F>));
+        }
         __syncthreads();
-        for (uint32_t s = NLT / 2; s > 0; s >>= 1) {
-            if (lt < s) {
+        // (with the pair kind the tree starts one level higher: a first round adds the bucket into leaf 0 -- same code, an extra trip)
+        for (uint32_t s = (HOT_GROUPS < NLT ? NLT / 2 : NLT); s > 0; s >>= 1) {
+            const bool extra = s == NLT;   // pair kind only: leaf 0 += the bucket's own sum
+            if (lt < s && (!extra || lt == 0)) {
                 BU<F> a = shh[threadIdx.x];
-                BU<F> bb = shh[threadIdx.x + s * T];
-                shh[threadIdx.x] = BU<F>::add_ni(a, bb);
+                BU<F> bb = extra ? load16<BU<F>>(dst) : shh[threadIdx.x + s * T];
+                shh[threadIdx.x] = tadd<F>(a, bb);
             }
             __syncthreads();
         }
-        if (lt == 0) {
-            BU<F> cur = load16<BU<F>>(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>));
-            store16(buckets + ((size_t)d.x * T + sub) * sizeof(BU<F>), BU<F>::add_ni(cur, shh[threadIdx.x]));
-        }
+        if (lt == 0) store16(dst, shh[threadIdx.x]);
         __syncthreads();
     }
 }

@@ -320,6 +320,7 @@ __global__ void __launch_bounds__(256) k_gen_points(Affine<F> gen, uint64_t seed
 template <class F>
 static int gen_points_t(msm_amd_ctx* ctx, const Affine<F>& gen, uint64_t seed, uint32_t first, uint32_t n, void* dev_out) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = msm_guard(ctx, 0, &k_gen_points<F>, "gen_points")) return rc;
     k_gen_points<F><<<(n + 255) / 256, 256, 0, ctx->stream>>>(gen, seed, first, n, (uint8_t*)dev_out);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipGetLastError());
@@ -349,7 +350,7 @@ static int conv_t(msm_amd_ctx* ctx, int which, uint32_t flags, const void* in, u
         (void)hipMemcpyAsync(di, in, in_b, hipMemcpyHostToDevice, st);
     }
     const uint32_t blocks = (n + 255) / 256;
-    if (which == 0) k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
+    if (which == 0) k_jacobian_to_affine<F><<<((n + jacobian_to_affine_points_per_lane<F>() - 1) / jacobian_to_affine_points_per_lane<F>() + 255) / 256, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
     else if (which == 1) k_batch_to_jacobian<F><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
     else if (which == 2) k_batch_lem_to_u<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
     else if (which == 3) k_batch_u_to_lem<F, B><<<blocks, 256, 0, st>>>((const uint8_t*)di, n, (uint8_t*)dout);
@@ -415,6 +416,8 @@ static int conv(msm_amd_ctx* ctx, int which, int curve, int group, uint32_t flag
 template <class F>
 static int in_curve_t(msm_amd_ctx* ctx, const F& b, uint32_t flags, const void* points, uint32_t n, uint8_t* out, bool group_check = false) {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (group_check)   // (its scalar multiplications call out-of-line point arithmetic: scratch on the queue, engine_ctx.hpp)
+        if (int rc = msm_guard(ctx, 0, &k_batch_in_group_affine<F>, "batch_in_group_affine")) return rc;
     hipStream_t st = ctx->stream;
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
     const size_t in_b = (size_t)n * sizeof(Affine<F>);

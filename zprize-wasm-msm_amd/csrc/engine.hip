@@ -23,7 +23,7 @@
 namespace msm {
 
 
-// launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2.hip
+// launchers of the bucket kernels, instantiated in bucket_g1_bls12381.hip / bucket_g1_bn254.hip / bucket_g2_*.hip
 template <class F, int VARIANT>
 void launch_accumulate(hipStream_t st, const uint8_t* bases, const uint8_t* xbeta, const uint32_t* sorted, const uint32_t* offset, const uint32_t* count,
                        const uint32_t* order, uint32_t nb, uint8_t* buckets, uint32_t seg, uint32_t seg_t, void* ctl, void* work, void* biglist);
@@ -97,6 +97,41 @@ void msm_set_err(msm_amd_ctx* ctx, const std::string& msg) {
     std::lock_guard<std::mutex> lk(g_err_mu);
     ctx->err = msg;
 }
+
+// Carries exactly MSM_SCRATCH_RESERVE bytes of private segment per lane; dispatched (one empty wave) on every stream of a new context so
+// that the runtime sizes every queue's scratch while a failure can still be reported (engine_ctx.hpp).
+__global__ void k_scratch_reserve(uint32_t* out, uint32_t n, uint32_t sel) {
+    if (n == 0) return;
+    constexpr int WORDS = (int)(MSM_SCRATCH_RESERVE / 4);
+    volatile uint32_t buf[WORDS];
+    for (int i = 0; i < WORDS; ++i) buf[i] = i * sel + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < n; ++i) acc += buf[(i * sel + acc) % WORDS];
+    out[threadIdx.x] = acc;
+}
+
+int msm_scratch_guard(msm_amd_ctx* ctx, int slot, const void* kernel, const char* what) {
+    hipFuncAttributes at;
+    if (hipFuncGetAttributes(&at, kernel) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;   // (no attributes, no verdict: launch as before)
+    }
+    const size_t need = at.localSizeBytes;
+    if (need <= ctx->scratch_level[slot].load()) return 0;   // the queue holds that much already: the runtime keeps what it has allocated
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (free_b < need * MSM_SCRATCH_SLOTS + MSM_SCRATCH_MARGIN) {
+        msm_set_err(ctx, std::string(what) + ": " + std::to_string(need) + " bytes of private segment per lane need " + std::to_string((need * MSM_SCRATCH_SLOTS) >> 20) +
+                             " MB of scratch on the queue, and the device has " + std::to_string(free_b >> 20) + " MB free (out of device memory)");
+        return MSM_AMD_ENOMEM;
+    }
+    ctx->scratch_level[slot].store(need);
+    return 0;
+}
+
 
 // mid_from / mid_below: the range of n that takes 14-bit windows of even width (0, 0 = none)
 static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, uint32_t nshards, uint32_t narrow_below, bool even = true, uint32_t mid_from = 0,
@@ -254,6 +289,10 @@ int MsmCall<F>::plan() {
         // with a full-size accumulation ~5 % (measured in round 1; at the end of round 3 a context runs its full-size calls at the same 2.59 ms
         // before and after small calls created this stream, profiles/r03_s2_state.txt); of another priority because only such streams never share a queue with S/A/B
         HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream_s2, hipStreamNonBlocking, 1));
+        // (a stream of another priority has a hardware queue of its own: its scratch like the others', engine_ctx.hpp)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b < MSM_SCRATCH_RESERVE * MSM_SCRATCH_SLOTS + MSM_SCRATCH_MARGIN) return msm_alloc_failed(ctx, "scratch of the second sort stream");
+        k_scratch_reserve<<<1, 64, 0, ctx->stream_s2>>>(nullptr, 0, 1);
     }
     st = small_est ? ctx->stream_s2 : ctx->stream_s;
     const bool dev_scalars = (a.flags & MSM_AMD_DEVICE_PTRS) != 0;
@@ -387,7 +426,7 @@ int MsmCall<F>::plan() {
     // ---- Jacobian bases -> affine
     if (jac) {
         if (int rc = ensure(ctx, sl->d_affine, (size_t)a.n * ASZ)) return rc;
-        uint32_t lanes = (a.n + 7) / 8;
+        uint32_t lanes = (a.n + jacobian_to_affine_points_per_lane<F>() - 1) / jacobian_to_affine_points_per_lane<F>();
         k_jacobian_to_affine<F><<<(lanes + 255) / 256, 256, 0, st>>>(d_bases, a.n, (uint8_t*)sl->d_affine.p);
         d_bases = (const uint8_t*)sl->d_affine.p;
     }
@@ -1237,6 +1276,32 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
                 delete ctx;
                 return MSM_AMD_EHIP;
             }
+    }
+    // scratch for the MSM path's kernels on every queue, now -- or the create fails cleanly (engine_ctx.hpp: a nearly full device would
+    // otherwise abort the process at some later dispatch).  HIP maps the streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default).
+    {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const size_t queues = std::min<size_t>(2 + 2 * msm_amd_ctx::MAX_SLOTS, q && atoi(q) > 0 ? (size_t)atoi(q) : 4);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < queues * MSM_SCRATCH_RESERVE * MSM_SCRATCH_SLOTS + MSM_SCRATCH_MARGIN) {
+            (void)hipGetLastError();
+            fprintf(stderr, "msm_amd_create: %zu MB of device memory free, %zu MB needed for the kernels' scratch on %zu hardware queues\n", free_b >> 20,
+                    (queues * MSM_SCRATCH_RESERVE * MSM_SCRATCH_SLOTS + MSM_SCRATCH_MARGIN) >> 20, queues);
+            msm_amd_destroy(ctx);
+            return MSM_AMD_ENOMEM;
+        }
+        std::vector<hipStream_t> all = {ctx->stream, ctx->stream_s};
+        for (Slot& sl : ctx->slots) {
+            all.push_back(sl.stream_b);
+            all.push_back(sl.stream_c);
+        }
+        for (hipStream_t st : all) k_scratch_reserve<<<1, 64, 0, st>>>(nullptr, 0, 1);
+        if (hipDeviceSynchronize() != hipSuccess || hipGetLastError() != hipSuccess) {
+            msm_amd_destroy(ctx);
+            return MSM_AMD_EHIP;
+        }
+        ctx->scratch_level[0].store(MSM_SCRATCH_RESERVE);
+        ctx->scratch_level[1].store(MSM_SCRATCH_RESERVE);
     }
     calibrate_streams(ctx);
     *out_ctx = ctx;

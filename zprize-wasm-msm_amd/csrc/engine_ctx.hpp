@@ -190,6 +190,7 @@ struct msm_amd_ctx {
     std::atomic<int> wide_hint{0};   // > 0: recent calls had scalars beyond the group order's bit length (entries in the overflow window): windows tile the declared width
     std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
+    std::atomic<size_t> scratch_level[2] = {};   // bytes per lane of private segment that streams A / S are known to hold scratch for (msm_scratch_guard)
     float timings[8] = {};
     uint32_t geometry[6] = {};
 };
@@ -202,6 +203,26 @@ inline bool msm_bases_lookup(msm_amd_ctx* ctx, const msm_amd_bases* h, int* curv
     *curve = h->curve;
     *group = h->group;
     return true;
+}
+
+// ---- scratch (private segments) ------------------------------------------------------------------------------------------------
+// A kernel that needs P bytes of private segment per lane makes the HSA runtime give the hardware queue it is dispatched on
+// P x 64 lanes x 8192 wave slots of scratch (measured: tools/microbench/scratch_dispatch.hip, profiles/r04_scratch_dispatch.txt), at
+// the dispatch, kept from then on, grown when a later kernel needs more.  When that allocation fails the runtime ABORTS THE PROCESS --
+// nothing a library can catch.  So: the kernels of the MSM path carry at most MSM_SCRATCH_RESERVE bytes (spills; their additions are
+// inlined: bucket_kernels.hpp; the build fails otherwise: tools/check_code_objects.py), and msm_amd_create dispatches a kernel with
+// exactly that much on every stream of the context after checking that the memory is there -- a device too full for it fails the
+// CREATE with MSM_AMD_ENOMEM.  The other entry points (group FFTs, batch conversions, the table build: 0.3-2.7 KB per lane, out-of-line
+// point arithmetic) ask msm_scratch_guard before they launch: it reads the kernel's private segment size from the code object
+// (hipFuncGetAttributes) and returns MSM_AMD_ENOMEM when the device could not take the queue's scratch plus a margin.
+constexpr size_t MSM_SCRATCH_RESERVE = 128;                    // bytes per lane reserved at create on every stream
+constexpr size_t MSM_SCRATCH_SLOTS = (size_t)64 * 8192;        // lanes the runtime sizes a queue's scratch for
+constexpr size_t MSM_SCRATCH_MARGIN = (size_t)64 << 20;
+// slot: 0 = stream A (conversions, FFTs), 1 = stream S (table build)
+int msm_scratch_guard(msm_amd_ctx* ctx, int slot, const void* kernel, const char* what);
+template <class K>
+inline int msm_guard(msm_amd_ctx* ctx, int slot, K* kernel, const char* what) {
+    return msm_scratch_guard(ctx, slot, reinterpret_cast<const void*>(kernel), what);
 }
 
 // Error text of a context.  Written by whichever thread fails (several may use one context: the libuv workers of the Node addon),
@@ -304,14 +325,17 @@ namespace msm {
 // Jacobian bases -> affine (g?m_multiexp entry point): Montgomery's trick, 8 points per lane
 // (build_curve_jacobian_a0.js:1040-1125 batchToAffine does the same thing sequentially).
 // ------------------------------------------------------------------------------------------
+// (every loop over the lane's points is fully unrolled, so that the prefix products stay in registers: indexed dynamically the array lived
+// in the private segment -- 400-784 bytes per lane, which the HSA runtime turns into up to 0.4 GB of scratch per hardware queue)
 template <class F>
 __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __restrict__ jac, uint32_t n, uint8_t* __restrict__ aff) {
-    constexpr int K = 8;
+    constexpr int K = sizeof(F) > 48 ? 4 : 8;   // points per lane (Fp2 elements are twice as wide: half as many keep the registers in bounds)
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t first = t * K;
     if (first >= n) return;
     F pref[K];
     F acc = F::one();
+#pragma unroll
     for (int k = 0; k < K; ++k) {
         uint32_t i = first + k;
         pref[k] = acc;
@@ -321,6 +345,7 @@ __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __res
         }
     }
     F inv = F::inv(acc);
+#pragma unroll
     for (int k = K - 1; k >= 0; --k) {
         uint32_t i = first + k;
         if (i >= n) continue;
@@ -337,6 +362,10 @@ __global__ void __launch_bounds__(256) k_jacobian_to_affine(const uint8_t* __res
         }
         store16(aff + (size_t)i * sizeof(Affine<F>), Affine<F>::canon(a));
     }
+}
+template <class F>
+constexpr uint32_t jacobian_to_affine_points_per_lane() {
+    return sizeof(F) > 48 ? 4u : 8u;
 }
 
 }  // namespace msm

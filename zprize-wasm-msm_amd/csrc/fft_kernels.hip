@@ -427,6 +427,7 @@ static int apply_key_t(msm_amd_ctx* ctx, uint32_t flags, const void* in, uint32_
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
     const size_t in_b = (size_t)n * (jac ? sizeof(Jacobian<F>) : sizeof(Affine<F>)), out_b = (size_t)n * sizeof(Jacobian<F>);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = jac ? msm_guard(ctx, 0, &k_batch_apply_key<F, true>, "batch_apply_key") : msm_guard(ctx, 0, &k_batch_apply_key<F, false>, "batch_apply_key")) return rc;
     hipStream_t st = ctx->stream;
     void *di = const_cast<void*>(in), *dout = out, *dkey = nullptr;
     if (dev && (((uintptr_t)in & 15) || ((uintptr_t)out & 15))) {
@@ -518,6 +519,8 @@ static int g_fft_t(msm_amd_ctx* ctx, uint32_t flags, const void* in, uint32_t n,
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0, inverse = (flags & MSM_AMD_FFT_INVERSE) != 0;
     const size_t bytes = (size_t)n * sizeof(Jacobian<F>);
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (int rc = msm_guard(ctx, 0, &k_g_fft_stage<F>, "group fft")) return rc;
+    if (int rc = msm_guard(ctx, 0, &k_g_fft_final<F>, "group fft")) return rc;
     hipStream_t st = ctx->stream;
     void *di = const_cast<void*>(in), *dout = out, *dx = nullptr, *dtw = nullptr;
     if (dev && (((uintptr_t)in & 15) || ((uintptr_t)out & 15))) {
@@ -562,6 +565,16 @@ static int fft_helper_t(msm_amd_ctx* ctx, int which, uint32_t flags, void* b1, v
     const bool dev = (flags & MSM_AMD_DEVICE_PTRS) != 0;
     const size_t bytes = (size_t)n * E::BYTES;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {   // (point elements: out-of-line point arithmetic, scratch on the queue -- engine_ctx.hpp; the Fr forms need none)
+        int rc = 0;
+        if (which == FFT_OP_JOIN) rc = msm_guard(ctx, 0, &k_fft_pair_op<E, FFT_OP_JOIN>, "fft_join");
+        else if (which == FFT_OP_JOIN_EXT) rc = msm_guard(ctx, 0, &k_fft_pair_op<E, FFT_OP_JOIN_EXT>, "fft_join_ext");
+        else if (which == FFT_OP_JOIN_EXT_INV) rc = msm_guard(ctx, 0, &k_fft_pair_op<E, FFT_OP_JOIN_EXT_INV>, "fft_join_ext");
+        else if (which == FFT_OP_PREP_LAGRANGE) rc = msm_guard(ctx, 0, &k_fft_pair_op<E, FFT_OP_PREP_LAGRANGE>, "prepare_lagrange_evaluation");
+        else if (which == 4) rc = msm_guard(ctx, 0, &k_fft_mix<E>, "fft_mix");
+        else rc = msm_guard(ctx, 0, &k_fft_final<E>, "fft_final");
+        if (rc) return rc;
+    }
     hipStream_t st = ctx->stream;
     if (dev && (((uintptr_t)b1 & 15) || ((uintptr_t)b2 & 15))) {
         msm_set_err(ctx, "device pointers must be 16-byte aligned");

@@ -118,6 +118,8 @@ static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, ui
     const size_t row = (size_t)h->stride * ASZ;
     h->table_bytes = (size_t)h->W * row;
     HIPCHK(ctx, hipMalloc(&h->table, h->table_bytes));
+    // (after the table has taken its share of the device: the doubling kernel's scratch must still fit -- engine_ctx.hpp)
+    if (int rc = msm_guard(ctx, 1, &k_table_next<F>, "prepare_bases")) return rc;
     hipStream_t st = ctx->stream_s;
     uint8_t* t0 = (uint8_t*)h->table;
     const bool dev = (flags & (MSM_AMD_DEVICE_PTRS | MSM_AMD_DEVICE_BASES)) != 0;
@@ -131,7 +133,7 @@ static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, ui
                 return MSM_AMD_EHIP;
             }
         }
-        k_jacobian_to_affine<F><<<((n + 7) / 8 + 255) / 256, 256, 0, st>>>((const uint8_t*)dj, n, t0);
+        k_jacobian_to_affine<F><<<((n + jacobian_to_affine_points_per_lane<F>() - 1) / jacobian_to_affine_points_per_lane<F>() + 255) / 256, 256, 0, st>>>((const uint8_t*)dj, n, t0);
         hipError_t e = hipStreamSynchronize(st);
         if (!dev) (void)hipFree(dj);
         HIPCHK(ctx, e);

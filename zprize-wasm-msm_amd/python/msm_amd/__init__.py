@@ -201,7 +201,7 @@ class Engine:
         ctx = ctypes.c_void_p()
         rc = self.L.msm_amd_create(int(device), ctypes.byref(ctx))
         if rc != 0:
-            raise MsmAmdError(f"msm_amd_create(device={device}) failed with {rc}: no usable MI355X / HIP runtime")
+            raise MsmAmdError(f"msm_amd_create(device={device}) failed with {rc}: " + ("the device has too little free memory for the kernels' scratch" if rc == ENOMEM else "no usable MI355X / HIP runtime"), rc)
         self.ctx = ctx
         self.device = device
 
