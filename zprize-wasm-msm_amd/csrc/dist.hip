@@ -99,7 +99,7 @@ int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
 // many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
 // tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
 // Other curves and groups scale the table; the choice of a split only needs its shape.
-static const float kShareMs[14][4] = {
+static const float kShareMsG1[14][4] = {
     {0.409f, 0.420f, 0.360f, 0.400f},       // 2^13
     {0.468f, 0.422f, 0.358f, 0.400f},       // 2^14
     {0.456f, 0.436f, 0.358f, 0.400f},       // 2^15
@@ -115,7 +115,43 @@ static const float kShareMs[14][4] = {
     {71.697f, 39.131f, 23.514f, 12.460f},   // 2^25
     {139.552f, 76.830f, 46.491f, 23.944f},  // 2^26
 };
-static double shard_cost_ms(uint32_t n_slice, uint32_t gw) {
+// The same for BN254 G1 and for G2 (round 4; tools/shard_table.py --curve bn128 / --group 2, profiles/r04_shard_table_*.txt, built with
+// tools/fit_share_tables.py: a cell is the best of two, three and four calls in flight; cells the sweeps did not visit are the G1 table's
+// scaled by the nearest measured cell).  BN254's cheaper field moves its cross-over between point slices and window groups to larger
+// shares than BLS12-381's; G2 (measured on BLS12-381, used for both curves' G2: the split only needs the table's shape) costs ~3x per point.
+static const float kShareMsBn254G1[14][4] = {
+    {0.246f, 0.253f, 0.217f, 0.241f},   // 2^13  (partly scaled from the G1 table)
+    {0.280f, 0.322f, 0.273f, 0.305f},   // 2^14  (partly scaled from the G1 table)
+    {0.286f, 0.325f, 0.257f, 0.287f},   // 2^15  (partly scaled from the G1 table)
+    {0.311f, 0.345f, 0.273f, 0.318f},   // 2^16
+    {0.364f, 0.378f, 0.297f, 0.310f},   // 2^17  (partly scaled from the G1 table)
+    {0.504f, 0.388f, 0.324f, 0.340f},   // 2^18
+    {0.839f, 0.471f, 0.343f, 0.333f},   // 2^19  (partly scaled from the G1 table)
+    {1.277f, 0.773f, 0.481f, 0.428f},   // 2^20
+    {2.534f, 1.502f, 0.870f, 0.625f},   // 2^21  (partly scaled from the G1 table)
+    {5.081f, 3.286f, 1.632f, 0.854f},   // 2^22
+    {10.511f, 5.480f, 3.363f, 1.786f},   // 2^23  (partly scaled from the G1 table)
+    {19.678f, 10.514f, 6.851f, 3.383f},   // 2^24
+    {37.126f, 20.572f, 13.592f, 6.502f},   // 2^25  (partly scaled from the G1 table)
+    {72.263f, 40.391f, 26.874f, 12.494f},   // 2^26  (partly scaled from the G1 table)
+};
+static const float kShareMsG2[14][4] = {
+    {0.464f, 0.477f, 0.408f, 0.454f},   // 2^13  (partly scaled from the G1 table)
+    {0.693f, 0.789f, 0.669f, 0.748f},   // 2^14  (partly scaled from the G1 table)
+    {0.915f, 0.810f, 0.596f, 0.666f},   // 2^15  (partly scaled from the G1 table)
+    {1.075f, 0.862f, 0.614f, 0.452f},   // 2^16
+    {1.565f, 1.037f, 0.683f, 0.713f},   // 2^17  (partly scaled from the G1 table)
+    {2.655f, 1.476f, 0.875f, 0.632f},   // 2^18
+    {4.410f, 2.367f, 1.346f, 1.307f},   // 2^19  (partly scaled from the G1 table)
+    {7.983f, 4.193f, 2.242f, 1.349f},   // 2^20
+    {15.210f, 8.047f, 4.213f, 3.026f},   // 2^21  (partly scaled from the G1 table)
+    {30.089f, 15.344f, 8.114f, 4.718f},   // 2^22
+    {54.587f, 27.441f, 15.745f, 8.835f},   // 2^23  (partly scaled from the G1 table)
+    {103.163f, 52.298f, 28.560f, 16.508f},   // 2^24  (partly scaled from the G1 table)
+    {194.634f, 102.323f, 56.663f, 31.723f},   // 2^25  (partly scaled from the G1 table)
+    {378.837f, 200.901f, 112.032f, 60.961f},   // 2^26  (partly scaled from the G1 table)
+};
+static double shard_cost_ms(const float (*kShareMs)[4], uint32_t n_slice, uint32_t gw) {
     if (n_slice == 0) return 0.0;
     const double lx = std::log2((double)n_slice), x = std::min(std::max(lx - 13.0, 0.0), 13.0);
     const double y = std::min(std::max(std::log2((double)gw), 0.0), 3.0);
@@ -136,9 +172,8 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
         *gp = world / ctx->dist_gw;
         return;
     }
-    (void)curve;
-    (void)group;
     (void)scalar_size;
+    const float (*table)[4] = group == 2 ? kShareMsG2 : (curve == MSM_AMD_BN128 ? kShareMsBn254G1 : kShareMsG1);
     // the split whose busiest rank -- slice 0, the longest -- is estimated fastest; near-ties (3 %) go to more point slices: the ranks
     // then hold less of the inputs
     double best = 1e300;
@@ -147,7 +182,7 @@ void msm_dist_split(const msm_amd_ctx* ctx, int curve, int group, uint32_t scala
         const uint32_t w = world / p;
         const uint32_t n_slice = (uint32_t)(((uint64_t)n + p - 1) / p);
         if (p > 1 && n_slice < 1024) continue;   // slices this small are all fixed cost
-        const double t = shard_cost_ms(n_slice, w);
+        const double t = shard_cost_ms(table, n_slice, w);
         if (t < best * 0.97) {
             best = t;
             *gw = w;
