@@ -278,7 +278,7 @@ def test_prepared_bases_match_oracle_for_every_window_layout(eng, orc, curve, gr
                 assert msm_amd.plan_prepared(curve, group, n, 0, c) == info      # the plan made without a GPU is the table that is built
                 bits = 255 if curve == "bls12381" else 254
                 assert info["scalar_bits"] == bits and info["windows"] * (info["c"] - 1) + info["signed_windows"] >= bits
-                assert info["signed_windows"] < info["windows"] and info["table_bytes"] == info["windows"] * ((n + 4095) // 4096 * 4096) * asz
+                assert info["signed_windows"] < info["windows"] and info["table_bytes"] == info["windows"] * ((n + 8191) // 8192 * 8192) * asz
                 eng.set_window_bits(0)                       # the call takes its layout from the table, not from the option
                 assert pb.multiexp(scalars) == exp, c
                 g = eng.geometry()

@@ -120,6 +120,48 @@ def test_work_list_in_sharded_and_prepared_calls(orc):
         eng.close()
 
 
+@pytest.mark.parametrize("curve,group,n,c,opts", [
+    ("bls12381", 1, 300000, 13, {"tile_mode": 2}),                    # 16 coarse bins, spans of 18750 entries: the 1024-lane fine sort reads them once
+    ("bls12381", 1, 60000, 18, {"tile_mode": 2, "sort_geom": 2}),     # 512 coarse bins, tiles of 8192 scalars, 256 fine buckets, the 256-lane fine sort
+    ("bn128", 1, 60000, 20, {"tile_mode": 2, "sort_geom": 3}),        # 512 bins, 1024 fine buckets, the 1024-lane fine sort
+    ("bn128", 1, 60000, 20, {"tile_mode": 2, "sort_geom": 2, "sort_big": 1}),   # 512 bins and the chunk-parallel kernels on 1024 fine buckets
+    ("bls12381", 2, 20000, 19, {"tile_mode": 2, "sort_geom": 3}),
+    ("bls12381", 1, 60000, 20, {"tile_mode": 2, "sort_geom": 1}),     # the round-3 geometry stays selectable
+])
+def test_partition_geometries_of_round_4(orc, curve, group, n, c, opts):
+    """The bucket sort's new shapes (csrc/engine.hip MsmCall::sort, csrc/sort_kernels.hpp): spans of up to 36864 entries read once by a
+    1024-lane workgroup, 512 coarse bins cut from tiles of 8192 scalars (13-bit ranks), the chunk-parallel kernels on 512 bins --
+    forced at sizes the oracle can follow (`tile_mode` = 2: the wide tiles these shapes belong to; `sort_geom`), synchronous and two
+    calls in flight, on caller-supplied bases and on a prepared table (merged windows: index slices over rows of 8192-padded stride)."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.set_window_bits(c)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, f"gpu:geom:{curve}:{group}:{n}:{c}", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        assert _f(C, group)(bases, scalars, 32, n) == exp
+        t1, t2 = C.multiexp_async(group, bases, scalars, 32, n), C.multiexp_async(group, bases, scalars, 32, n)
+        assert t1.wait() == exp and t2.wait() == exp
+        pb = C.prepare_bases(group, bases, n)
+        try:
+            assert pb.info()["table_bytes"] == pb.info()["windows"] * ((n + 8191) // 8192 * 8192) * C.affine_bytes(group)
+            assert pb.multiexp(scalars) == exp
+        finally:
+            pb.release()
+        # half the scalars equal: one long span per window, whatever the geometry
+        skew = bytearray(scalars)
+        for i in range(0, n, 2):
+            skew[32 * i:32 * i + 32] = scalars[:32]
+        skew = bytes(skew)
+        assert _f(C, group)(bases, skew, 32, n) == O.normalize(O.multiexp_affine(bases, skew, 32, n))
+    finally:
+        eng.close()
+
+
 def test_release_of_a_prepared_table_is_atomic_with_submissions(orc):
     """msm_amd_release_bases and the submission of a call on the table share one critical section: while one thread
     keeps calls in flight on a table, another thread's release is refused ("still in flight") or, once it succeeds, every later call is

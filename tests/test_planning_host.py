@@ -61,7 +61,7 @@ def test_prepared_layouts_cover_the_scalars_exactly(curve, group):
                 except msm_amd.MsmAmdError as e:
                     # refused only when no window size keeps windows x (padded) points below 2^31
                     assert e.code == msm_amd.EINVAL
-                    stride = (n + 4095) & ~4095
+                    stride = (n + 8191) & ~8191
                     assert ((bits or 255) + 21) // 21 * stride >= 1 << 31, (n, bits, forced)
                     continue
                 c, W, ns, sb = p["c"], p["windows"], p["signed_windows"], p["scalar_bits"]
@@ -70,7 +70,7 @@ def test_prepared_layouts_cover_the_scalars_exactly(curve, group):
                 assert W == (sb + c) // c and 0 <= ns <= max(W - 1, 0)          # the fewest windows; the top one unsigned
                 assert _start_bit(c, ns, W) >= sb                              # they cover the scalar ...
                 assert ns == 0 or _start_bit(c, ns - 1, W) < sb                # ... with the fewest signed ones
-                stride = (n + 4095) & ~4095
+                stride = (n + 8191) & ~8191
                 assert W * stride < 1 << 31 and p["table_bytes"] == W * stride * AFFINE[(curve, group)]
                 if forced and W * stride < 1 << 31:
                     assert c >= forced                                         # a forced size is kept unless the table would not fit

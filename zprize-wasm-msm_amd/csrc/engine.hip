@@ -492,9 +492,50 @@ int MsmCall<F>::sort() {
 
     // ---- 1. populations of the (owned window, coarse bin) pairs -- digits recomputed from the scalars, never stored
     SortGeom sg;
+    // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
+    // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
+    // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
+    // 100 KB of LDS has to wait for a whole CU to drain of the long-running accumulation waves of the calls already in flight: with
+    // another call pending the small tiles give the better THROUGHPUT up to n = 2^22 (n = 2^20: 2.59-2.60 against 2.62-2.63 ms per
+    // MSM, 2^22: 10.80 against 10.95; equal from 2^24), and for the ranks of a many-way shard, which keep four calls in flight, at
+    // every size (8 ranks: n = 2^20 0.74 -> 0.70 ms per call, 2^22 2.19 -> 2.00, 2^26 24.7 -> 24.2; 2 % the other way at 4 ranks).
+    const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
     // fine key: 8 bits up to c = 17 (at c = 16: 128 coarse bins, spans of n / 128 entries -- one workgroup reads a span once up
     // to n = 2^20 -- and runs of tile / 128 entries in the partition), then 8 coarse bits and the rest fine
     sg.fbits = g.c - 1 <= 16u ? std::min(g.c - 1, 8u) : g.c - 1 - 8u;
+    // Round 4: what a (window, coarse bin) span may hold and still be read ONCE by one workgroup grew from 9216 to 36864 entries
+    // (k_fine_small on 1024 lanes, FINE_CAP_WIDE), and the partition may cut 512 coarse bins (tiles of 8192 scalars, two windows per
+    // phase: the runs keep their 16 entries).  Spans that fit are sorted in one pass -- read, LDS permutation, one coalesced stream out --
+    // instead of the three passes and 16-byte runs of the chunk-parallel kernels: n = 2^22 at c = 16 (128 bins), 2^23 at c = 19 (256),
+    // 2^24 at c = 20 (512), the merged windows of a prepared table at n = 2^20 (512).  Beyond (n >= 2^25) the chunk-parallel kernels
+    // stay, on 512 bins where the window allows it: half as many fine buckets per chunk, runs twice as long.  Option "sort_geom" = 1
+    // keeps the round-3 geometry (256 bins, 9216-entry spans).
+    bool fine_wide = false, tile8k = false;
+    {
+        auto fits = [&](uint32_t fb, uint32_t cap) {
+            const uint64_t m = (uint64_t)nve >> (g.c - 1 - fb);
+            return m + 6 * (uint64_t)std::ceil(std::sqrt((double)m)) <= cap && ((size_t)2 * (1u << fb) + cap) * 4 + 8192 <= 160 * 1024;
+        };
+        const bool merged_ok = !g.merged || g.stride % 8192u == 0;   // (a tile of scalars must not straddle an index slice: rows of the table are `stride` apart)
+        // (512 bins double the histogram's counters and their flush: below ~2^24 entries -- a prepared table at n = 2^20 -- the round-3
+        // shape stays ahead, 0.22 against 0.235 ms for the stage)
+        const bool may8k = wide && g.c - 1 > 16u && g.c <= 20 && !use_glv && merged_ok && ctx->sort_geom != 1 && (nve >= (1u << 24) || ctx->sort_geom >= 2);
+        if (ctx->sort_geom >= 2 && may8k) {   // tests: the 512-bin partition (and, = 3, the wide fine sort) at sizes an oracle can follow
+            sg.fbits = g.c - 1 - 9u;
+            tile8k = true;
+            fine_wide = ctx->sort_geom == 3 || (!fits(sg.fbits, FINE_CAP) && fits(sg.fbits, FINE_CAP_WIDE));
+        } else if (ctx->sort_geom != 1 && wide && !fits(sg.fbits, FINE_CAP)) {
+            if (fits(sg.fbits, FINE_CAP_WIDE)) {
+                fine_wide = true;
+            } else if (may8k && fits(g.c - 1 - 9u, FINE_CAP_WIDE)) {
+                sg.fbits = g.c - 1 - 9u;
+                fine_wide = tile8k = true;
+            } else if (may8k) {
+                sg.fbits = g.c - 1 - 9u;
+                tile8k = true;
+            }
+        }
+    }
     sg.cbits = g.c - 1 - sg.fbits;
     sg.cb = 1u << sg.cbits;
     sg.nbins = g.Wl * sg.cb;
@@ -512,14 +553,6 @@ int MsmCall<F>::sort() {
         return MSM_AMD_EINVAL;
     }
     const size_t nsub = (size_t)sg.nbins * sg.S;   // bins the partition scatters into
-    // tiles: 4096 items (1024 lanes x 4) from n = 2^19 -- runs of tile / cb = 32 entries (one 128-byte line) per (tile, window,
-    // bin), one reservation per run; smaller inputs take tiles of 1024 (256 lanes x 4) so that more than a handful of CUs work
-    // The wide tiles are the faster sort on an idle chip (n = 2^20: 128 against 156 us for the stage), but a 1024-lane workgroup with
-    // 100 KB of LDS has to wait for a whole CU to drain of the long-running accumulation waves of the calls already in flight: with
-    // another call pending the small tiles give the better THROUGHPUT up to n = 2^22 (n = 2^20: 2.59-2.60 against 2.62-2.63 ms per
-    // MSM, 2^22: 10.80 against 10.95; equal from 2^24), and for the ranks of a many-way shard, which keep four calls in flight, at
-    // every size (8 ranks: n = 2^20 0.74 -> 0.70 ms per call, 2^22 2.19 -> 2.00, 2^26 24.7 -> 24.2; 2 % the other way at 4 ranks).
-    const bool wide = ctx->tile_mode ? ctx->tile_mode == 2 : (nv >= (1u << 19) && g.nshards <= 4 && !(others_pending && g.nshards == 1 && nv < (1u << 23)));
     const uint32_t tile = wide ? 4096u : 1024u;
     const uint32_t ntile = (nv + tile - 1) / tile;
     // chunks of the spans that are cut up (k_big_*): 8192 entries for 1024-lane workgroups on an idle chip, 4096 for 256-lane ones
@@ -535,7 +568,7 @@ int MsmCall<F>::sort() {
     if (int rc = ensure(ctx, sl->d_binhist, nsub * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_binstart, (nsub + 1) * 4)) return rc;
     if (int rc = ensure(ctx, sl->d_bincur, nsub * 4)) return rc;
-    if (int rc = ensure(ctx, sl->d_cpre, ((size_t)sg.nbins + 1) * 4)) return rc;
+    if (int rc = ensure(ctx, sl->d_cpre, (std::max<size_t>(sg.nbins, 64) + 1) * 4)) return rc;   // (also the 64 range sums of the parallel bin scan)
     if (int rc = ensure(ctx, sl->d_desc, max_chunks * 8)) return rc;
     if (int rc = ensure(ctx, sl->d_bcursor, (size_t)NB * 4)) return rc;
     uint32_t* binhist = (uint32_t*)sl->d_binhist.p;
@@ -578,7 +611,13 @@ int MsmCall<F>::sort() {
 #undef MSM_TILE_HIST
     HIPCHK(ctx, hipEventRecord(sl->ev[2], st));
     // ---- 2. bin starts
-    k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, sg.S, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
+    if (nsub > 32768 && ctx->sort_geom != 1) {   // many bins (large n): the scan by up to 64 workgroups, two short launches (cpre is free until the fine sort plans its chunks)
+        const uint32_t sgrid = (uint32_t)std::min<size_t>(64, (nsub + 4095) / 4096);
+        k_bin_scan_sums<<<sgrid, 1024, 0, st>>>(binhist, sg.nbins, sg.S, cpre);
+        k_bin_scan_ranges<<<sgrid, 1024, 0, st>>>(binhist, sg.nbins, sg.S, cpre, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
+    } else {
+        k_bin_scan<<<1, 1024, 0, st>>>(binhist, sg.nbins, sg.S, binstart, bincur, bins, 2u * (uint32_t)ORDER_KEYS);
+    }
     sl->binhist_zero.set(sl->d_binhist);
     HIPCHK(ctx, hipEventRecord(sl->ev[3], st));
     // ---- 3. partition by coarse bin, fine sort inside each bin (emits count/offset), ordering by population
@@ -596,7 +635,17 @@ do {                                                                            
 do {                                    \
     MSM_TILE_SCATTER(NW, BL, uint32_t, 4);          \
 } while (0)
-    if (wide) {
+    if (tile8k) {   // 8192 scalars per tile, two windows per phase: 512 coarse bins with runs of 16 entries
+        constexpr size_t lds8 = tile_scatter_lds<uint32_t>(8192, 2, 1024);
+        const uint32_t ntile8 = (nv + 8191u) / 8192u;
+        if (nw == 8) {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<8, 8, 1024, uint32_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            k_tile_scatter<8, 8, 1024, uint32_t, 2><<<ntile8, 1024, lds8, st>>>(d_items, g, sg, bincur, (uint32_t*)sl->d_tmp.p);
+        } else {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tile_scatter<0, 8, 1024, uint32_t, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+            k_tile_scatter<0, 8, 1024, uint32_t, 2><<<ntile8, 1024, lds8, st>>>(d_items, g, sg, bincur, (uint32_t*)sl->d_tmp.p);
+        }
+    } else if (wide) {
         if (nw == 8) MSM_TILE_SCATTER_E(8, 1024);
         else if (nw == 4) MSM_TILE_SCATTER_E(4, 1024);
         else MSM_TILE_SCATTER_E(0, 1024);
@@ -609,20 +658,33 @@ do {                                    \
 #undef MSM_TILE_SCATTER
     const uint32_t nf = 1u << sg.fbits;
     const size_t bnd_lds = sg.S > 1 ? ((size_t)sg.S + 1) * 4 : 0;   // sub-bin boundaries of one span
-    const size_t small_lds = ((size_t)2 * nf + FINE_CAP) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * chunk) * 4 + bnd_lds;
-    // Spans up to FINE_CAP entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
+    const uint32_t cap = fine_wide ? (uint32_t)FINE_CAP_WIDE : (uint32_t)FINE_CAP;   // what one fine-sort workgroup reads in one go
+    const size_t small_lds = ((size_t)2 * nf + cap) * 4 + bnd_lds, nf_lds = (size_t)nf * 4, big_lds = ((size_t)2 * nf + 2 * chunk) * 4 + bnd_lds;
+    // Spans up to `cap` entries: one workgroup each, read once.  Longer ones -- large n, the dense bins of a partly used top
     // window -- are cut into chunks that workgroups sort in parallel (k_big_*, five more launches); when none is expected those
     // launches are skipped and an unexpected long span (adversarial scalars) is sorted by its one workgroup, chunk by chunk.
     // (a prepared table's windows all fill the bucket set evenly: no partly used top window)
     const uint32_t tb = (g.merged || g.ns != g.W) ? 0u : (g.nbits > (g.W - 1) * g.c ? g.nbits - (g.W - 1) * g.c : 0u);   // scalar bits in the top window
     const uint64_t mean_span = (uint64_t)nve / sg.cb;
-    const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)FINE_CAP || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)FINE_CAP) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
-    if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
-    }
+    const bool expect_long = mean_span + 6 * (uint64_t)std::ceil(std::sqrt((double)mean_span)) > (uint64_t)cap || (tb > 0 && tb < g.c - 1 && (uint64_t)nv > (uint64_t)cap) || ctx->sort_big == 1 || (ctx->sort_big == 0 && ctx->skew_hint.load() > 0);
+    auto fine_small = [&](bool long_here) -> int {
+        if (fine_wide) {
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true, FINE_BLOCK_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false, FINE_BLOCK_WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            if (long_here) k_fine_small<uint32_t, true, FINE_BLOCK_WIDE><<<sg.nbins, FINE_BLOCK_WIDE, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+            else k_fine_small<uint32_t, false, FINE_BLOCK_WIDE><<<sg.nbins, FINE_BLOCK_WIDE, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+            return 0;
+        }
+        if (small_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+            HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fine_small<uint32_t, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_lds));
+        }
+        if (long_here) k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        else k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        return 0;
+    };
     if (!expect_long || ctx->sort_big == 2) {
-        k_fine_small<uint32_t, true><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        if (int rc = fine_small(true)) return rc;
     } else {
         if (big_lds > 64 * 1024) {   // beyond the default dynamic-LDS limit (the CU has 160 KB)
             HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_big_scatter<uint32_t, 1024, BIG_CHUNK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
@@ -630,11 +692,11 @@ do {                                    \
         }
         const uint32_t big_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 4096);   // a multiple of 8: one share per XCD
         HIPCHK(ctx, hipMemsetAsync(count, 0, (size_t)NB * 4, st));   // the buckets of cut-up spans are counted with atomics
-        k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, chunk, cpre);
+        k_big_plan<<<1, 1024, 0, st>>>(binstart, sg.nbins, sg.S, chunk, cap, cpre);
         k_big_desc<<<(uint32_t)std::min<size_t>((max_chunks + 255) / 256, 1024), 256, 0, st>>>(binstart, cpre, sg.nbins, sg.S, chunk, desc);
-        k_fine_small<uint32_t, false><<<sg.nbins, SORT_BLOCK, small_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, sg, g.half, sorted, count, offset);
+        if (int rc = fine_small(false)) return rc;
         k_big_hist<uint32_t><<<big_grid, SORT_BLOCK, nf_lds, st>>>((const uint32_t*)sl->d_tmp.p, binstart, cpre, desc, sg, g.half, chunk, count);
-        k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, count, offset, bcursor);
+        k_big_offsets<<<sg.nbins, SORT_BLOCK, nf_lds, st>>>(binstart, sg, g.half, cap, count, offset, bcursor);
         // one resident wave of workgroups, one per CU, each XCD walking its own eighth of the chunk list in order (see the kernel)
         const uint32_t bigs_grid = (uint32_t)std::min<size_t>((max_chunks + 7) / 8 * 8, 256);
         if (small_chunks) {
@@ -1410,6 +1472,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
     if (!strcmp(name, "dist_timeout_ms")) { ctx->dist_timeout_ms.store(value); return 0; }   // how long an exchange of a multi-GPU group waits for its peers (0 = for ever)
     if (!strcmp(name, "dist_gw")) { ctx->dist_gw = value; return 0; }   // window groups of a sharded call of a multi-GPU group (0 = chosen per call)
+    if (!strcmp(name, "sort_geom")) { ctx->sort_geom = value; return 0; }       // experiments / tests: 0 = round 4's geometry by size, 1 = round 3's (256 coarse bins, 9216-entry spans), 2 = 512 bins wherever the window allows, 3 = 2 + the 1024-lane fine sort
     if (!strcmp(name, "chunk_mode")) { ctx->chunk_mode = value; return 0; }     // experiments: chunk-parallel fine sort, 1 = 4096-entry chunks / 256 lanes, 2 = 8192 / 1024, 0 = by what else is in flight
     if (!strcmp(name, "tile_mode")) { ctx->tile_mode = value; return 0; }       // experiments: 1 = tiles of 1024 scalars, 2 = of 4096, 0 = by size
     if (!strcmp(name, "acc_stream")) { ctx->acc_stream = value; return 0; }     // experiments: 1 = the slot's stream, 2 = the context's stream A

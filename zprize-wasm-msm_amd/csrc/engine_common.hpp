@@ -55,7 +55,7 @@ MSM_HD uint32_t items_ni(uint32_t key, uint32_t T, uint32_t osh) {
     return ni < 1u ? 1u : (ni > ITEMS_NI_MAX ? ITEMS_NI_MAX : ni);
 }
 
-constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 8 coarse + 12 fine bits of bucket index (the sort's two levels, sort_kernels.hpp)
+constexpr int MAX_WINDOW_BITS = 21;   // widest window: sign + 20 bits of bucket index (8-9 coarse + 11-12 fine: the sort's two levels; the partition packs the index beside a 12-bit rank, sort_kernels.hpp)
 
 // Window geometry shared by host and kernels.
 struct Geom {

@@ -96,7 +96,7 @@ struct msm_amd_bases {
     msm_amd_ctx* ctx = nullptr;
     int curve = 0, group = 0;
     uint32_t n = 0;             // points
-    uint32_t stride = 0;        // points per table row: n rounded up to the sort's largest tile (4096), so that a tile of scalars never straddles an index slice
+    uint32_t stride = 0;        // points per table row: n rounded up to the sort's largest tile (8192), so that a tile of scalars never straddles an index slice
     uint32_t scalar_bits = 0;   // the windows cover scalars below 2^scalar_bits
     uint32_t c = 0, W = 0, ns = 0;   // window layout (Geom: ns windows of c bits, signed, then W - ns of c - 1 bits, unsigned)
     void* table = nullptr;      // [W][stride] affine points, the reference's packed Montgomery image: table[w][i] = 2^(start bit of window w) * P_i
@@ -178,7 +178,7 @@ struct msm_amd_ctx {
     int no_hot = 0;         // option "hot" = 0: no short segments / grouped fold for hot buckets
     int zero_copy = 1;      // option "zero_copy" (default 1): the reduction writes its partials and the tail words straight into the pinned host buffer -- no copy back (15 us of every call); 0 = device buffer + one copy
     int no_split2 = 0;      // option "split2" = 0: one lane per bucket always (switches k_accumulate_slices off)
-    uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0, chunk_mode = 0;
+    uint32_t acc_variant = 0, acc_stream = 0, tile_mode = 0, chunk_mode = 0, sort_geom = 0;
     int items_mode = 0;     // option "items": the accumulation's work list (0 = by launch size, 1 = wherever the populations allow, 2 = never)
     uint32_t items_t = 0;   // option "items_t": entries per lane of the work list (0 = chosen per launch)
     uint32_t splitk = 0;    // option "splitk": lanes per bucket of the G1 accumulation, 0 = chosen per launch, 1..MAX_SLICES forced

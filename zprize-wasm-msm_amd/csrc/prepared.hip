@@ -64,7 +64,7 @@ static void plan_prepared(uint32_t n, uint32_t bits, uint32_t forced_c, uint32_t
         // W windows, ns of them signed (c bits), cover W (c - 1) + ns bits; ns <= W - 1 because the top window is unsigned
         *W = (bits + c) / c;                                     // = ceil((bits + 1) / c)
         *ns = bits > *W * (c - 1) ? bits - *W * (c - 1) : 0u;
-        return (uint64_t)*W * (((uint64_t)n + 4095u) & ~4095ull) < (1ull << 31);   // (table rows are padded to 4096 points)
+        return (uint64_t)*W * (((uint64_t)n + 8191u) & ~8191ull) < (1ull << 31);   // (table rows are padded to 8192 points)
     };
     *c_out = *W_out = *ns_out = 0;
     uint32_t want = forced_c;
@@ -114,7 +114,7 @@ static int build_table(msm_amd_ctx* ctx, msm_amd_bases* h, const void* bases, ui
     const size_t ASZ = sizeof(Affine<F>), JSZ = sizeof(Jacobian<F>);
     const uint32_t n = h->n;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    h->stride = (n + 4095u) & ~4095u;
+    h->stride = (n + 8191u) & ~8191u;   // the sort's largest tile (8192 scalars, round 4): a tile never straddles an index slice
     const size_t row = (size_t)h->stride * ASZ;
     h->table_bytes = (size_t)h->W * row;
     HIPCHK(ctx, hipMalloc(&h->table, h->table_bytes));
@@ -237,7 +237,7 @@ int msm_amd_plan_prepared(int curve, int group, uint32_t n, uint32_t scalar_bits
     out6[4] = ns;
     out6[5] = 1u << (c - 1);
     const uint64_t affine = (uint64_t)2 * (curve == MSM_AMD_BLS12381 ? 48 : 32) * (uint64_t)group;
-    if (table_bytes) *table_bytes = (uint64_t)W * (((uint64_t)n + 4095u) & ~4095ull) * affine;
+    if (table_bytes) *table_bytes = (uint64_t)W * (((uint64_t)n + 8191u) & ~8191ull) * affine;
     return 0;
 }
 

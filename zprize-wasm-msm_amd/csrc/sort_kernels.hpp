@@ -31,9 +31,9 @@
 namespace msm {
 
 constexpr int SORT_BLOCK = 256;
-constexpr int COARSE_MAX = 256;        // coarse bins per window (8 bits)
+constexpr int COARSE_MAX = 512;        // coarse bins per window (9 bits: round 4 -- 8 until then)
 constexpr int FINE_MAX_BITS = 12;      // fine buckets per coarse bin (4096)
-static_assert(MAX_WINDOW_BITS == 1 + 8 + FINE_MAX_BITS, "sign + coarse + fine bits of a window (engine_common.hpp)");
+static_assert(MAX_WINDOW_BITS <= 1 + 9 + FINE_MAX_BITS && MAX_WINDOW_BITS - 1 + 12 <= 32, "sign + coarse + fine bits of a window; bucket index and a 12-bit rank share a word (k_tile_scatter)");
 
 // Bits [pos, pos+nb) of scalar i (nb <= 25, as build_multiexp.js:25-94); bytes past the scalar read 0.
 MSM_D uint32_t scalar_bits(const uint8_t* scalars, const Geom& g, uint32_t i, uint32_t pos, uint32_t nb) {
@@ -300,6 +300,67 @@ __global__ void __launch_bounds__(1024) k_bin_scan(uint32_t* __restrict__ binhis
     for (uint32_t i = t; i < n_order_bins; i += 1024) order_bins[i] = 0;
 }
 
+// The same scan by SEVERAL workgroups, for the bin counts of large calls (213 000 bins at n = 2^26: the single workgroup took 0.32 ms):
+// pass A leaves the population of every workgroup's contiguous (parent-major) range of bins in blocksum[], pass B starts each range at
+// the sum of the ranges before it.  gridDim.x <= 64.
+__global__ void __launch_bounds__(1024) k_bin_scan_sums(const uint32_t* __restrict__ binhist, uint32_t nparent, uint32_t S, uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t t = threadIdx.x, nbins = nparent * S;
+    const uint32_t range = (nbins + gridDim.x - 1) / gridDim.x, r0 = min(blockIdx.x * range, nbins), r1 = min(r0 + range, nbins);
+    auto src_of = [&](uint32_t i) { return S > 1 ? (i % S) * nparent + i / S : i; };
+    uint32_t sum = 0;
+    for (uint32_t i = r0 + t; i < r1; i += 1024) sum += binhist[src_of(i)];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_down(sum, d, 64);
+    if ((t & 63u) == 0) wsum[t >> 6] = sum;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < 16; ++q) tot += wsum[q];
+        blocksum[blockIdx.x] = tot;
+    }
+}
+__global__ void __launch_bounds__(1024) k_bin_scan_ranges(uint32_t* __restrict__ binhist, uint32_t nparent, uint32_t S, const uint32_t* __restrict__ blocksum,
+                                                           uint32_t* __restrict__ binstart, uint32_t* __restrict__ cursor, uint32_t* __restrict__ order_bins,
+                                                           uint32_t n_order_bins) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t t = threadIdx.x, nbins = nparent * S;
+    const uint32_t range = (nbins + gridDim.x - 1) / gridDim.x, r0 = min(blockIdx.x * range, nbins), r1 = min(r0 + range, nbins);
+    uint32_t base = 0, grand = 0;
+    for (uint32_t w = 0; w < gridDim.x; ++w) {   // (at most 64 values, the same for every lane: scalar loads)
+        const uint32_t v = blocksum[w];
+        if (w < blockIdx.x) base += v;
+        grand += v;
+    }
+    const uint32_t per = (r1 - r0 + 1023u) / 1024u, lo = min(r0 + t * per, r1), hi = min(lo + per, r1);
+    auto src_of = [&](uint32_t i) { return S > 1 ? (i % S) * nparent + i / S : i; };
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += binhist[src_of(i)];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)(t & 63u) >= d) incl += o;
+    }
+    if ((t & 63u) == 63u) wsum[t >> 6] = incl;
+    __syncthreads();
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (uint32_t q = 0; q < 16; ++q)
+        if (q < (t >> 6)) run += wsum[q];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t src = src_of(i), v = binhist[src];
+        binstart[i] = run;
+        cursor[src] = run;
+        binhist[src] = 0;
+        run += v;
+    }
+    if (blockIdx.x == 0) {
+        if (t == 0) binstart[nbins] = grand;
+        for (uint32_t i = t; i < n_order_bins; i += 1024) order_bins[i] = 0;
+    }
+}
+
 // partition entry
 template <class E>
 MSM_D E make_entry(uint32_t idx, bool neg, uint32_t fine, uint32_t idxbits);
@@ -360,7 +421,10 @@ template <int NW, int ITEMS, int BLOCK, class E, int GW>
 __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restrict__ scalars, Geom g, SortGeom sg, uint32_t* __restrict__ cursor,
                                                          E* __restrict__ tmp) {
     constexpr int T = ITEMS * BLOCK;
-    static_assert(T <= 4096, "ranks are packed into 12 bits");
+    // (bucket index << RB) | rank inside the run: 12 bits of rank for tiles up to 4096 items (bucket indices up to 20 bits: c <= 21),
+    // 13 for the 8192-item tiles of the 512-bin partition (bucket indices up to 19 bits: c <= 20 -- the engine only pairs them so)
+    constexpr uint32_t RB = T <= 4096 ? 12u : 13u;
+    static_assert(T <= 8192, "ranks are packed into 12 or 13 bits");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem_raw[];
     E* stage = reinterpret_cast<E*>(smem_raw);                                  // [GW * T] entries grouped by run
     uint32_t* hs = reinterpret_cast<uint32_t*>(stage + GW * T);                 // [GW * cb] counts, then the start of each run in `stage`
@@ -372,7 +436,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
     ds.load(scalars, g, tile * T);
     const uint32_t ncnt = GW * sg.cb;
     for (uint32_t w0 = 0; w0 < g.W; w0 += GW) {
-        // (bucket index = magnitude - 1, < 2^20) << 12 | rank inside the run (< 4096).  Validity is kept apart (livem): with the
+        // (bucket index = magnitude - 1, < 2^20) << RB | rank inside the run (< T).  Validity is kept apart (livem): with the
         // magnitude itself packed, a digit of exactly 2^20 (c = 21) shifted out of the word -- the entry was dropped or indexed LDS
         // out of bounds -- and every value of the packed word is a legitimate (bucket, rank) pair, so none is free as a marker.
         uint32_t mr[GW][ITEMS];
@@ -396,7 +460,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
                     if (neg) negm[gw] |= 1u << k;
                     if (owned && mag != 0) {
                         livem[gw] |= 1u << k;
-                        mr[gw][k] = ((mag - 1) << 12) | atomicAdd(&hs[gw * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
+                        mr[gw][k] = ((mag - 1) << RB) | atomicAdd(&hs[gw * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
                     }
                 }
             }
@@ -416,7 +480,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_scatter(const uint8_t* __restric
 #pragma unroll
             for (int k = 0; k < ITEMS; ++k) {
                 if ((livem[gw] >> k) & 1u) {
-                    const uint32_t b = mr[gw][k] >> 12, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & 0xfffu);
+                    const uint32_t b = mr[gw][k] >> RB, run = gw * sg.cb + (b >> sg.fbits), slot = hs[run] + (mr[gw][k] & ((1u << RB) - 1u));
                     // (prepared bases: the entry addresses the table point of this window, w * stride + i)
                     const uint32_t index = (g.merged ? (w0 + gw) * g.stride : 0u) + ds.first + k * BLOCK;
                     stage[slot] = make_entry<E>(sg.S > 1 ? index & ((1u << sg.idxbits) - 1u) : index, (negm[gw] >> k) & 1u, b & ((1u << sg.fbits) - 1u), sg.idxbits);
@@ -454,26 +518,31 @@ MSM_D uint32_t order_key(uint32_t b, uint32_t cnt, uint32_t split, uint32_t osh)
 // fine sort of one (window, coarse bin) span: bucket count / offset tables and the index lists grouped by bucket
 // ------------------------------------------------------------------------------------------
 constexpr int FINE_ITEMS = 37;                         // entries per lane held in registers: nine 16-byte vectors + one head / tail entry
-constexpr int FINE_CAP = 36 * SORT_BLOCK;              // 9216: spans up to this size are read once by one workgroup
+constexpr int FINE_CAP = 36 * SORT_BLOCK;              // 9216: spans up to this size are read once by one 256-lane workgroup
+// Round 4: the same kernel with 1024 lanes reads spans up to 36864 entries once (147 KB of LDS for the permuted span: one workgroup
+// per CU) -- n = 2^23 at 256 coarse bins, n = 2^24 at 512, the merged windows of a prepared table at n = 2^20: sizes that used to go
+// through the chunk-parallel kernels (three passes, 16-byte runs).  `cap` (a launch parameter of the k_big_* kernels) = FINE_CAP or this.
+constexpr int FINE_BLOCK_WIDE = 1024;
+constexpr int FINE_CAP_WIDE = 36 * FINE_BLOCK_WIDE;
 
 // LONG_HERE: spans beyond FINE_CAP are handled by this workgroup too (chunk by chunk: histogram sweep, then chunk-wise counting
 // sort with stores by bucket runs) -- the form launched when no long span is expected, so that an unexpected one (adversarial
 // scalars at small n) is still sorted correctly, just by a single workgroup.  Otherwise they are left to the k_big_* kernels.
-template <class E, bool LONG_HERE>
-__global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half,
+template <class E, bool LONG_HERE, int FB = SORT_BLOCK>
+__global__ void __launch_bounds__(FB) k_fine_small(const E* __restrict__ tmp, const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half,
                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ count, uint32_t* __restrict__ offset) {
     extern __shared__ uint32_t smem_u32[];
     const uint32_t nf = 1u << sg.fbits;
     uint32_t* h = smem_u32;                 // [nf]   bucket populations, then exclusive starts
     uint32_t* out = smem_u32 + 2 * nf;      // [FINE_CAP] the span (or one chunk of it), grouped by bucket
-    __shared__ uint32_t wsum[SORT_BLOCK / 64];
+    __shared__ uint32_t wsum[FB / 64];
     const uint32_t bin = blockIdx.x;                              // = wl * cb + coarse bin
     const uint32_t start = binstart[bin * sg.S], end = binstart[(bin + 1) * sg.S];
     const uint32_t span = end - start, t = threadIdx.x;
     // sub-bin boundaries of this span (S > 1: the entries keep the low bits of their index, the sub-bin is the rest)
-    uint32_t* bnd = smem_u32 + 2 * nf + FINE_CAP;                 // [S + 1]
+    uint32_t* bnd = smem_u32 + 2 * nf + 36 * FB;                 // [S + 1]
     if (sg.S > 1) {
-        for (uint32_t i = t; i <= sg.S; i += SORT_BLOCK) bnd[i] = binstart[bin * sg.S + i];
+        for (uint32_t i = t; i <= sg.S; i += FB) bnd[i] = binstart[bin * sg.S + i];
         __syncthreads();
     }
     auto high_bits = [&](uint32_t pos) -> uint32_t {              // of the entry at position `pos` of the span
@@ -481,36 +550,36 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
     };
     const uint32_t wl = bin / sg.cb, cbin = bin % sg.cb;
     const uint32_t gb0 = wl * half + (cbin << sg.fbits);
-    if (span > (uint32_t)FINE_CAP) {
+    if (span > (uint32_t)(36 * FB)) {
         if constexpr (LONG_HERE) {
             uint32_t* th = smem_u32 + nf;   // [nf] chunk: counts, then exclusive starts inside the chunk
-            for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
+            for (uint32_t i = t; i < nf; i += FB) h[i] = 0;
             __syncthreads();
-            for (uint32_t p = start + t; p < end; p += SORT_BLOCK) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
+            for (uint32_t p = start + t; p < end; p += FB) atomicAdd(&h[entry_fine(tmp[p], sg.idxbits)], 1u);
             __syncthreads();
-            for (uint32_t i = t; i < nf; i += SORT_BLOCK) count[gb0 + i] = h[i];
+            for (uint32_t i = t; i < nf; i += FB) count[gb0 + i] = h[i];
             __syncthreads();
-            block_exclusive_scan(h, nf, wsum);
-            for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
+            block_exclusive_scan<FB>(h, nf, wsum);
+            for (uint32_t i = t; i < nf; i += FB) offset[gb0 + i] = start + h[i];
             // h[f]: next free position of bucket f relative to `start`
-            for (uint32_t cbeg = start; cbeg < end; cbeg += FINE_CAP) {
-                const uint32_t cn = min((uint32_t)FINE_CAP, end - cbeg);
-                for (uint32_t i = t; i < nf; i += SORT_BLOCK) th[i] = 0;
+            for (uint32_t cbeg = start; cbeg < end; cbeg += 36 * FB) {
+                const uint32_t cn = min((uint32_t)(36 * FB), end - cbeg);
+                for (uint32_t i = t; i < nf; i += FB) th[i] = 0;
                 __syncthreads();
-                for (uint32_t s = t; s < cn; s += SORT_BLOCK) {
+                for (uint32_t s = t; s < cn; s += FB) {
                     const E e = tmp[cbeg + s];
                     const uint32_t f = entry_fine(e, sg.idxbits);
                     const uint32_t r = atomicAdd(&th[f], 1u);
                     sorted[start + h[f] + r] = entry_sorted(e, sg.idxbits) + high_bits(cbeg - start + s);   // h is not modified during this loop
                 }
                 __syncthreads();
-                for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] += th[i];
+                for (uint32_t i = t; i < nf; i += FB) h[i] += th[i];
                 __syncthreads();
             }
         }
         return;
     }
-    for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = 0;
+    for (uint32_t i = t; i < nf; i += FB) h[i] = 0;
     __syncthreads();
     E e[FINE_ITEMS];
     uint32_t rank[FINE_ITEMS];
@@ -534,19 +603,19 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
                 return 0xffffffffu;
             }
             if (k >= 4 * NV) return 0xffffffffu;
-            const uint32_t v = (uint32_t)(k >> 2) * SORT_BLOCK + t;
+            const uint32_t v = (uint32_t)(k >> 2) * FB + t;
             return v < nvec ? head + 4u * v + (uint32_t)(k & 3) : 0xffffffffu;
         } else {
-            const uint32_t s2 = (uint32_t)k * SORT_BLOCK + t;
+            const uint32_t s2 = (uint32_t)k * FB + t;
             return s2 < span ? s2 : 0xffffffffu;
         }
     };
     if constexpr (VEC) {
-        static_assert(NV * 4 * SORT_BLOCK + 8 >= FINE_CAP, "the register slots cover a span of FINE_CAP entries");
+        static_assert(NV * 4 * FB + 8 >= 36 * FB, "the register slots cover a span of FINE_CAP entries");
         const uint4* vp = reinterpret_cast<const uint4*>(tmp + start + head);
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const uint32_t v = (uint32_t)j * SORT_BLOCK + t;
+            const uint32_t v = (uint32_t)j * FB + t;
             if (v < nvec) {
                 const uint4 q = vp[v];
                 e[4 * j] = q.x;
@@ -568,24 +637,24 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_fine_small(const E* __restrict__
     for (int k = 0; k < FINE_ITEMS; ++k)
         if (slot_of(k) != 0xffffffffu) rank[k] = atomicAdd(&h[entry_fine(e[k], sg.idxbits)], 1u);
     __syncthreads();
-    for (uint32_t i = t; i < nf; i += SORT_BLOCK) count[gb0 + i] = h[i];
+    for (uint32_t i = t; i < nf; i += FB) count[gb0 + i] = h[i];
     __syncthreads();
-    block_exclusive_scan(h, nf, wsum);
-    for (uint32_t i = t; i < nf; i += SORT_BLOCK) offset[gb0 + i] = start + h[i];
+    block_exclusive_scan<FB>(h, nf, wsum);
+    for (uint32_t i = t; i < nf; i += FB) offset[gb0 + i] = start + h[i];
 #pragma unroll
     for (int k = 0; k < FINE_ITEMS; ++k)
         if (slot_of(k) != 0xffffffffu) out[h[entry_fine(e[k], sg.idxbits)] + rank[k]] = entry_sorted(e[k], sg.idxbits) + high_bits(slot_of(k));
     __syncthreads();
     if constexpr (VEC) {
         uint4* op = reinterpret_cast<uint4*>(sorted + start + head);
-        for (uint32_t v = t; v < nvec; v += SORT_BLOCK) {
+        for (uint32_t v = t; v < nvec; v += FB) {
             const uint32_t* src = out + head + 4u * v;
             op[v] = make_uint4(src[0], src[1], src[2], src[3]);
         }
         if (t < head) sorted[start + t] = out[t];
         if (t >= 4 && t - 4 < ntail) sorted[start + head + 4u * nvec + (t - 4)] = out[head + 4u * nvec + (t - 4)];
     } else {
-        for (uint32_t s2 = t; s2 < span; s2 += SORT_BLOCK) sorted[start + s2] = out[s2];
+        for (uint32_t s2 = t; s2 < span; s2 += FB) sorted[start + s2] = out[s2];
     }
 }
 
@@ -604,7 +673,7 @@ constexpr int BIG_CHUNK = BIG_ITEMS * SORT_BLOCK;   // 8192 entries (16384 were 
 // (twelve of them hold 107 KB of LDS and every register), a 256-lane one with 41 KB fits beside them as soon as one wave per SIMD retires.
 constexpr int BIG_CHUNK_SMALL = 4096;
 
-__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t S, uint32_t chunk, uint32_t* __restrict__ cpre) {
+__global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ binstart, uint32_t nbins, uint32_t S, uint32_t chunk, uint32_t cap, uint32_t* __restrict__ cpre) {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
     const uint32_t t = threadIdx.x;
@@ -615,7 +684,7 @@ __global__ void __launch_bounds__(1024) k_big_plan(const uint32_t* __restrict__ 
         uint32_t v = 0;
         if (i < nbins) {
             const uint32_t span = binstart[(i + 1) * S] - binstart[i * S];
-            v = span > (uint32_t)FINE_CAP ? (span + chunk - 1) / chunk : 0u;
+            v = span > cap ? (span + chunk - 1) / chunk : 0u;   // (cap: what the fine-sort kernel of this launch reads in one go)
         }
         uint32_t incl = v;
 #pragma unroll
@@ -668,13 +737,13 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_big_hist(const E* __restrict__ t
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half, const uint32_t* __restrict__ count,
+__global__ void __launch_bounds__(SORT_BLOCK) k_big_offsets(const uint32_t* __restrict__ binstart, SortGeom sg, uint32_t half, uint32_t cap, const uint32_t* __restrict__ count,
                                                              uint32_t* __restrict__ offset, uint32_t* __restrict__ bcursor) {
     extern __shared__ uint32_t smem_u32[];
     uint32_t* h = smem_u32;   // [nf]
     __shared__ uint32_t wsum[SORT_BLOCK / 64];
     const uint32_t bin = blockIdx.x, start = binstart[bin * sg.S], t = threadIdx.x, nf = 1u << sg.fbits;
-    if (binstart[(bin + 1) * sg.S] - start <= (uint32_t)FINE_CAP) return;
+    if (binstart[(bin + 1) * sg.S] - start <= cap) return;
     const uint32_t gb0 = (bin / sg.cb) * half + ((bin % sg.cb) << sg.fbits);
     for (uint32_t i = t; i < nf; i += SORT_BLOCK) h[i] = count[gb0 + i];
     __syncthreads();
