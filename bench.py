@@ -401,6 +401,7 @@ def main():
     result = res if res is not None else result
     sync()
     elapsed = time.perf_counter() - t0
+    hints = eng.hints()        # the context's call-to-call state as the timed region left it (wide / skew layouts, work list)
     if sharded:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -436,29 +437,40 @@ def main():
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         # HBM bytes of one k_accumulate launch from the hardware counters (rocprofv3 --pmc, its own run: profiles/pmc_accumulate.json);
         # only quoted for the workload it was measured on
+        # only quoted for the workload they were measured on: profiles/pmc_accumulate_<curve>_g<group>_2p<logn>.json (tools/make_pmc_summaries.py;
+        # the headline's also under the old name profiles/pmc_accumulate.json), window layout checked
         traffic = None
-        headline = (args.curve, g, args.logn) == ("bls12381", 1, 20) and geom["c"] == 16 and geom["windows"] == 17 and not sharded and prep is None
-        pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
-        if headline and os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        key = f"{args.curve}_g{g}_2p{args.logn}"
+        plain = not sharded and prep is None
+
+        def counters(kind):
+            for name in (f"pmc_{kind}_{key}.json",) + ((f"pmc_{kind}.json",) if key == "bls12381_g1_2p20" else ()):
+                path = os.path.join(ROOT, "profiles", name)
+                if plain and os.path.exists(path):
+                    try:
+                        doc = json.load(open(path))
+                    except Exception:
+                        continue
+                    if doc.get("window_bits", geom["c"]) == geom["c"] and doc.get("windows", geom["windows"]) == geom["windows"]:
+                        return doc
+            return None
+
+        doc_a, doc_s = counters("accumulate"), counters("scatter")
+        if doc_a:
+            traffic = doc_a.get("hbm_bytes_per_launch")
         # scatter stage (histogram + scan/order + scatter): B_scatter = 32 + 4*W per pair
         sc_ms = stages.get("histogram", 0) + stages.get("scan_order", 0) + stages.get("scatter", 0)
         iso_src = iso if iso else stages
         acc_iso = iso_src.get("accumulate", 0.0)
         sc_iso = iso_src.get("histogram", 0) + iso_src.get("scan_order", 0) + iso_src.get("scatter", 0)
         sc_bytes = n * 32 + geom["entries"] * 4
-        sc_traffic = sc_per_kernel = None
-        pmc_s = os.path.join(ROOT, "profiles", "pmc_scatter.json")
-        if os.path.exists(pmc_s) and headline:
-            try:
-                doc = json.load(open(pmc_s))
-                sc_traffic = doc.get("hbm_bytes_per_call")
-                sc_per_kernel = doc.get("per_kernel")     # {kernel: {us, moved MB, GB/s on moved bytes}}: measured with rocprofv3, this workload only
-            except Exception:
-                sc_traffic = None
+        sc_traffic = doc_s.get("hbm_bytes_per_call") if doc_s else None
+        sc_per_kernel = doc_s.get("per_kernel") if doc_s else None     # {kernel: {us, moved MB, GB/s on moved bytes}}: measured with rocprofv3, this workload only
+        # what a TWO-LEVEL partition can reach on this figure of merit: it reads the scalars twice (digits are recomputed, never stored),
+        # writes the 4-byte entries, reads them, writes the index lists -- 64 + 12 W bytes per pair against the algorithmic 32 + 4 W --
+        # and the chip's streaming-copy rate is ~6.3 of the 8 TB/s
+        w_eff = geom["entries"] / max(1, n)
+        sc_ceiling = (6300.0 / HBM_PEAK_GBS) * (32 + 4 * w_eff) / (64 + 12 * w_eff)
         mads = MADS_PER_ADD.get((args.curve, g))
         out = {
             "metric": ("BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
@@ -475,7 +487,8 @@ def main():
                                   **prep.info(), "prepare_s": t_prep}),
                        "parallelism": "1 GPU" if not sharded else f"{plan['gp']} point slices x {plan['gw']} window groups over {world} GPUs (every rank holds only its slice) + ONE RCCL all_gather of the partials",
                        "split": None if not sharded else {"gp": plan["gp"], "gw": plan["gw"], "points_per_rank": count},
-                       "exchange": exchange, "rccl_ranks": rccl_ranks},
+                       "exchange": exchange, "rccl_ranks": rccl_ranks,
+                       "hints_after_timed_region": hints},
             "mode": (f"pipelined({depth}): {depth} calls in flight, every call collected inside the timed region" if pipelined else "one call at a time"),
             # the dominant kernel is integer-ALU bound: its roofline is the VALU issue rate of v_mad_u64_u32 (MADS_PER_ADD of them per
             # bucket addition, field_u.hpp / curve_u.hpp).  Peak: measured on this chip with tools/microbench/valu_rates.hip
@@ -500,7 +513,7 @@ def main():
                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                           "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": acc_ms,
                           "avg_launch_ms_one_call_at_a_time": acc_iso}),
-            "roofline_scatter": {"kernels": "k_tile_hist + k_bin_scan + k_tile_scatter + k_fine_small (k_big_* for long spans) + k_order_hist + k_order_scatter (HBM-bound stage, csrc/sort_kernels.hpp)", "bound": "hbm",
+            "roofline_scatter": {"kernels": "k_tile_hist + k_bin_scan[_sums/_ranges] + k_tile_scatter + k_fine_small (k_big_* for spans beyond one workgroup) + k_order_hist + k_order_scatter [+ k_items_plan] (HBM-bound stage, csrc/sort_kernels.hpp)", "bound": "hbm",
                                  "achieved": (sc_bytes / (sc_ms * 1e-3) / 1e9) if sc_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (sc_bytes / (sc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_ms > 0 else 0.0,
                                  "algorithmic_bytes": sc_bytes, "avg_ms": sc_ms,
@@ -509,8 +522,10 @@ def main():
                                  "per_kernel": sc_per_kernel,
                                  "avg_ms_one_call_at_a_time": sc_iso,
                                  "frac_one_call_at_a_time": (sc_bytes / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if sc_iso > 0 else None,
-                                 "traffic_frac_of_peak": (sc_traffic / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_iso > 0) else None},
-            "latency": ({"what": "wall time of one synchronous msm_amd_multiexp call, inputs resident, nothing else in flight",
+                                 "traffic_frac_of_peak": (sc_traffic / (sc_iso * 1e-3) / 1e9 / HBM_PEAK_GBS) if (sc_traffic and sc_iso > 0) else None,
+                                 "ceiling": {"frac": sc_ceiling, "derivation": "a two-level partition moves at least 64 + 12 W bytes per pair (scalars read twice, 4-byte entries written and read, "
+                                             "index lists written) for the algorithmic 32 + 4 W, at ~6.3 TB/s of streaming copies: (6.3 / 8) x (32 + 4 W) / (64 + 12 W), W = entries per pair"}},
+            "latency": ({"what": ("wall time of one synchronous msm_amd_multiexp_prepared call" if prep is not None else "wall time of one synchronous msm_amd_multiexp call") + ", inputs resident, nothing else in flight",
                          "runs": len(lat_ms), "median_ms": lat_ms[len(lat_ms) // 2], "min_ms": lat_ms[0], "max_ms": lat_ms[-1],
                          "pairs_per_s_at_median": n / (lat_ms[len(lat_ms) // 2] * 1e-3)} if lat_ms else None),
             "stages_ms": stages,

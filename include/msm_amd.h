@@ -75,29 +75,51 @@ void msm_amd_destroy(msm_amd_ctx *ctx);
 const char *msm_amd_last_error(const msm_amd_ctx *ctx);
 /* Optional tuning: window size c in bits (0 = automatic). */
 int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
-/* Tuning / test knobs (0 = automatic): "window_bits", "segment" (max entries one lane adds before a long
- * bucket is cut into parallel segments), "reduce_l" (buckets per lane in the bucket reduction),
- * "sort_big" (fine sort of long spans: 0 = chunk-parallel kernels where long spans are expected, 1 = always, 2 = never), "slots" (calls in flight, 1..8),
- * "split" (1 = reduce a lone call's windows in two overlapping groups; measured slower, off by default),
- * "glv" (0 never | 1 (default) where it pays AND the call carries MSM_AMD_BASES_IN_SUBGROUP | 2 whenever it applies, the option itself
- * being the caller's word that the bases lie in the order-r subgroup: the GLV schedule of BLS12-381 G1),
- * "slice" (points per pass of a synchronous call, default 2^26; larger inputs are processed slice by slice),
- * "split2" (0 = one lane per bucket always; default 1: G1 launches with few buckets cut their buckets into slices, one lane each), "splitk" (lanes per
- * bucket of such a launch: 0 = chosen per launch, 1..64 forced), "splitk_lanes" (the lane count that choice
- * brings a launch with few buckets to, default 327680), "reduce_pair" (1 = the G1 reduction with every point on a lane pair; measured
- * no faster, off by default), "even_windows" (default 1: when the window size does not divide the scalar width the windows are
- * c and c - 1 bits wide and tile the width that 32-byte scalars are EXPECTED to use -- the group order's: 255 / 254 bits -- exactly, with one
- * more window for the bits above, which reduced scalars leave empty; scalars that do use those bits give the same result as ever and switch the
- * following calls of the context to windows over all 256 bits; 0 = windows of c bits only, the round-2 layout),
- * "hot" (default 1: a bucket that holds more than 32 x the segment length -- a witness full of ones puts most points into one bucket -- is cut into
- * short segments and its segment sums are folded by 32 workgroups; 0 = the ordinary segment path, for before / after measurements; with the
- * environment variable MSM_AMD_DEBUG_TAIL set every collected call prints its segment / long-bucket / hot-bucket counts to stderr),
- * "zero_copy" (default 1: the window partials are written by the reduction kernel straight into pinned host memory; 0 = into a device
- * buffer that is copied back),
- * "dist_gw" (window groups of a call of a multi-GPU group: 0 = planned per call, else a divisor of the world size); for experiments only: "acc_variant" (build of the G1 accumulation kernel: 0 by launch size, 1 two
- * interleaved multiply-add chains, 2 one chain), "acc_stream" (0 by launch size, 1 the slot's own stream, 2 the context's stream A),
- * "tile_mode" (scalars per tile of the partition: 0 by size and load, 1 = 1024, 2 = 4096) and "chunk_mode" (entries per chunk of the
- * chunk-parallel fine sort: 0 by size and load, 1 = 4096 on 256-lane workgroups, 2 = 8192 on 1024-lane ones). */
+/* Options of a context (msm_amd_set_option; 0 = automatic unless stated).  Environment: MSM_AMD_C, MSM_AMD_SEG, MSM_AMD_REDUCE_L
+ * (= window_bits, segment, reduce_l at create), MSM_AMD_DIST_TIMEOUT_MS, MSM_AMD_RCCL_LIB (the collective library of a multi-GPU
+ * group, default librccl.so.1), MSM_AMD_NO_CALIBRATE (keep the streams in creation order), MSM_AMD_DEBUG_TAIL (print segment / long
+ * bucket / hot bucket counts of every collected call).
+ *
+ *   -- what a host may want to set -------------------------------------------------------------------------------------------------
+ *   slots            calls in flight per context, 1..8 (default 2); each slot owns its scratch: HBM per slot below
+ *   window_bits      window size c in bits, <= 21 (also msm_amd_set_window_bits); at msm_amd_prepare_bases: the table's window size
+ *   slice            points per pass of a synchronous call (default 2^26); larger inputs are processed slice by slice
+ *   glv              0 never | 1 (default) where it pays AND the call carries MSM_AMD_BASES_IN_SUBGROUP | 2 whenever it applies (the option
+ *                    itself being the caller's word that the bases lie in the order-r subgroup): the GLV schedule of BLS12-381 G1
+ *   even_windows     default 1: when c does not divide the scalar width the windows are c and c - 1 bits wide and tile the width that
+ *                    32-byte scalars are EXPECTED to use (the group order's: 255 / 254 bits) exactly, with one more window for the bits
+ *                    above, which reduced scalars leave empty; scalars that do use those bits give the same result and switch the next
+ *                    16 calls of the context to windows over all 256 bits.  0 = windows of c bits only (the round-2 layout)
+ *   zero_copy        default 1: the window partials are written by the reduction kernel straight into pinned host memory
+ *   dist_gw          window groups of a call of a multi-GPU group (0 = planned per call, else a divisor of the world size); must be the
+ *                    same on every rank (checked in the exchange: MSM_AMD_EINVAL on every rank otherwise)
+ *   dist_timeout_ms  how long an exchange of a multi-GPU group waits for its peers (default 300000; 0 = for ever); after that the
+ *                    communicator is aborted and the group is dead (msm_amd_dist_wait)
+ *
+ *   -- tests and before / after measurements (results are identical whatever they are set to) ---------------------------------------
+ *   segment          max entries one lane adds before a long bucket is cut into segments for the tail kernels (tests force splitting)
+ *   hot              default 1: a bucket beyond 32 x the segment length is cut into short segments folded by 32 workgroups; 0 = ordinary segments
+ *   items            the accumulation's work list (lanes per bucket in proportion to its population): 0 where a launch is short of filling
+ *                    the chip, 1 wherever the populations allow, 2 never;   items_t: entries per lane of the work list (0 = per launch)
+ *   split2           default 1: launches with few, long buckets cut them into slices; 0 = one lane per bucket always
+ *   splitk           lanes per bucket of a sliced launch (0 = per launch, 1..64 forced);   splitk_lanes: the lane count it aims at (default 327680)
+ *   sort_big         fine sort of spans beyond one workgroup: 0 chunk-parallel kernels where such spans are expected, 1 always, 2 never
+ *   sort_geom        partition geometry: 0 round 4's by size, 1 round 3's (256 coarse bins, 9216-entry spans), 2 = 512 bins wherever the
+ *                    window allows, 3 = 2 + the 1024-lane fine sort
+ *   reduce_l         buckets per lane of the bucket reduction (a power of two)
+ *
+ *   -- experiments that were measured and left off, kept for re-measurement ---------------------------------------------------------
+ *   split (1 = reduce a lone call's windows in two overlapping groups: slower), reduce_pair (1 = the G1 reduction on lane pairs: no gain),
+ *   acc_variant (build of the G1 accumulation: 1 two interleaved multiply-add chains, 2 one chain), acc_stream (1 the slot's stream, 2
+ *   stream A), tile_mode (scalars per partition tile: 1 = 1024, 2 = 4096), chunk_mode (chunk-parallel fine sort: 1 = 4096-entry chunks on
+ *   256 lanes, 2 = 8192 on 1024)
+ *
+ * HBM a context holds beside the caller's inputs: per slot, the scratch of its largest call so far -- at n = 2^20 (BLS12-381 G1, 16-bit
+ * windows): 64 MiB partition entries + 64 MiB index lists + 119 MiB buckets + ~0.3 GB for the segment lists of skewed inputs (sized for the
+ * worst case: every entry in a hot bucket: up to 2^20 + entries / segment segments of one bucket image each; 0.6 GB for G2) + 6 MiB of
+ * counters; at n = 2^26 (20-bit windows) ~13 GiB.  Per context: ~70 MB of kernel scratch per hardware queue (GPU_MAX_HW_QUEUES, default
+ * 4), reserved by msm_amd_create -- which fails with MSM_AMD_ENOMEM when the device cannot hold it: an exhausted device then yields
+ * error codes, never an abort.  Prepared tables are extra (msm_amd_plan_prepared says how much). */
 int msm_amd_set_option(msm_amd_ctx *ctx, const char *name, uint32_t value);
 /* Diagnostic: out[11*11]; out[i*11+j] = 1 when streams i and j (the context's A, S, B0, C0, B1, C1, B2, C2, B3, C3; 10 = the null stream) share a
  * hardware queue (their kernels serialise).  HIP maps streams onto hardware queues in creation order across the whole process, and
@@ -187,10 +209,18 @@ int msm_amd_combine(int curve, int group, const uint8_t *partials, uint32_t coun
  *                                                        points (6 GiB of bases at n = 2^26 become 0.75 GiB per GPU at gp = 8)
  *                msm_amd_dist_destroy(ctx)            (also done by msm_amd_destroy)
  * The asynchronous pair keeps several calls in flight per rank (up to `slots`).  Every rank must SUBMIT the same calls in the same
- * order; the exchanges then happen in that order on every rank, whatever the order and the threads in which the tickets are waited
- * for (every ticket must be waited for: a later one waits for its turn).  A call whose part cannot be queued or fails on one rank still
- * completes on all: that rank gets its own error, the others MSM_AMD_EPEER -- nobody is left waiting in a collective.
- * RCCL is dlopen'ed on first use.  With more than four ranks export GPU_MAX_HW_QUEUES=8 before the process
+ * order; the exchanges then happen in that order on every rank.  The tickets may be waited for in ANY order and from any threads: a
+ * wait for a later ticket performs the exchanges of the earlier ones on the way and parks their results for whoever asks for them
+ * (every ticket must still be waited for, or the group left with msm_amd_dist_destroy, which collects the rest).  A call whose part cannot
+ * be queued or fails on one rank still completes on all: that rank gets its own error, the others MSM_AMD_EPEER.  The ranks' headers are
+ * compared in every exchange: ranks that planned different splits of the call, or different window layouts inside one point slice
+ * (options that differ between ranks), get MSM_AMD_EINVAL on EVERY rank instead of a sum of partials that do not belong together.
+ * Nobody is left waiting in a collective: an exchange is bounded by option "dist_timeout_ms" (default 5 minutes); when the peers do not
+ * arrive, or the collective fails locally, the communicator is aborted (ncclCommAbort) and the group is DEAD on this rank -- the call,
+ * every pending ticket and every later call of the group return MSM_AMD_EPEER at once, plain calls on the context keep working, and
+ * msm_amd_dist_destroy + a new msm_amd_dist_init on every rank bring the group back.
+ * RCCL is dlopen'ed on first use (MSM_AMD_RCCL_LIB names another library with the same entry points: the tests' shared-memory
+ * stand-in, tests/host/fake_rccl.c).  With more than four ranks export GPU_MAX_HW_QUEUES=8 before the process
  * starts (read by the HIP runtime at start-up; msm_amd_dist_init warns when it is missing).                                    */
 int msm_amd_dist_unique_id(uint8_t *out128);
 int msm_amd_dist_init(msm_amd_ctx *ctx, int rank, int world, const uint8_t *id128);
@@ -350,6 +380,10 @@ int msm_amd_get_timings(const msm_amd_ctx *ctx, float *ms, int capacity);
 /* Window geometry of the last call: [0] c, [1] windows W, [2] buckets per window, [3] windows processed,
  * [4],[5] low/high word of the number of (pair, window) entries scattered into buckets */
 int msm_amd_get_geometry(const msm_amd_ctx *ctx, uint32_t *out6);
+/* The call-to-call state that shapes a context's next calls: [0] calls left in the wide layout (recent scalars used
+ * bits beyond the group order's width), [1] calls left expecting skew (recent calls queued over-long buckets), [2] slots, [3] entries per
+ * lane of the accumulation's work list in the call planned last (0: one lane per bucket, or slices).  A measurement reports them. */
+int msm_amd_get_hints(const msm_amd_ctx *ctx, uint32_t *out4);
 
 #ifdef __cplusplus
 }

@@ -470,6 +470,7 @@ int MsmCall<F>::plan() {
     // whose mean needs more than ITEMS_NI_MAX / 2 lanes (a handful of very long buckets: small n in 8-bit windows) keep the sliced
     // launch with its tree join.  Option "items": 0 = by this rule, 1 = wherever the mean allows, 2 = never.
     items_T = items_osh = 0;
+    ctx->last_items_T = 0;
     {
         const uint64_t entries = (uint64_t)g.Wl * nve;
         const uint32_t lanes_goal = KernelField<F>::chained_variant ? ctx->splitk_lanes : ctx->splitk_lanes / 3u;
@@ -480,6 +481,7 @@ int MsmCall<F>::plan() {
         const bool wanted = ctx->items_mode == 1 || (ctx->items_mode == 0 && NB < lanes_goal);
         if (fits && wanted && !split_mode && !ctx->no_split2 && !ctx->splitk && !ctx->force_seg) {
             items_T = T;
+            ctx->last_items_T = T;
             while (((uint64_t)(ITEMS_CLASSES - 1) << items_osh) < (uint64_t)ITEMS_NI_MAX * T) ++items_osh;   // every population the lanes cover lies inside a class
         }
     }
@@ -1668,6 +1670,14 @@ int msm_amd_get_timings(const msm_amd_ctx* ctx, float* ms, int capacity) {
     int k = std::min(capacity, 8);
     for (int i = 0; i < k; ++i) ms[i] = ctx->timings[i];
     return k;
+}
+int msm_amd_get_hints(const msm_amd_ctx* ctx, uint32_t* out4) {
+    if (!ctx || !out4) return MSM_AMD_EINVAL;
+    out4[0] = (uint32_t)std::max(0, ctx->wide_hint.load());
+    out4[1] = (uint32_t)std::max(0, ctx->skew_hint.load());
+    out4[2] = ctx->nslots;
+    out4[3] = ctx->last_items_T;
+    return 0;
 }
 int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out6) {
     if (!ctx || !out6) return MSM_AMD_EINVAL;

@@ -191,6 +191,7 @@ struct msm_amd_ctx {
     std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
     std::atomic<size_t> scratch_level[2] = {};   // bytes per lane of private segment that streams A / S are known to hold scratch for (msm_scratch_guard)
+    uint32_t last_items_T = 0;   // entries per lane of the work list in the call planned last (0: it ran one lane per bucket or slices)
     float timings[8] = {};
     uint32_t geometry[6] = {};
 };

@@ -268,6 +268,13 @@ class Engine:
         names = ["gpu_total", "histogram", "scan_order", "scatter", "accumulate", "reduce", "host_combine", "to_affine"]
         return {names[i]: float(arr[i]) for i in range(k)}
 
+    def hints(self):
+        """msm_amd_get_hints: the call-to-call state of the context -- {wide, skew: calls left in that layout, slots, work_list_T}"""
+        arr = (ctypes.c_uint32 * 4)()
+        self.L.msm_amd_get_hints.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.L.msm_amd_get_hints(self.ctx, arr)
+        return {"wide": arr[0], "skew": arr[1], "slots": arr[2], "work_list_T": arr[3]}
+
     def geometry(self):
         arr = (ctypes.c_uint32 * 6)()
         self.L.msm_amd_get_geometry(self.ctx, arr)
