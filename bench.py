@@ -255,7 +255,9 @@ def main():
     exchange = None
     if sharded:
         exchange = "torch.distributed all_gather_into_tensor (msm_amd.dist)"
-        if backend == "nccl":
+        # (MSM_AMD_RCCL_LIB names another collective library for the engine -- the tests' shared-memory stand-in: then the C-ABI exchange is
+        # rehearsed under the gloo backend too, ranks sharing one GPU, which RCCL itself refuses)
+        if backend == "nccl" or os.environ.get("MSM_AMD_RCCL_LIB"):
             # the ranks agree on the outcome: rank 0 broadcasts the id or a failure marker unconditionally, and the C-ABI exchange is
             # used only if msm_amd_dist_init succeeded on EVERY rank (a rank falling back on its own would leave the others in
             # ncclCommInitRank or in a collective nobody else enters)
@@ -273,7 +275,7 @@ def main():
                     ok = 1
                 except msm_amd.MsmAmdError as e:
                     print(f"bench.py: msm_amd_dist_init failed on rank {rank} ({e})", file=sys.stderr)
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            flag = torch.tensor([ok], dtype=torch.int32, device=xdev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 exchange = "C ABI: msm_amd_multiexp_dist_local_async / msm_amd_dist_wait (ncclAllGather on the engine's own communicator)"

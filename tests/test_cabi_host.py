@@ -91,3 +91,18 @@ def test_montgomery_conversion_matches_reference(msm, curve):
             assert msm.f_from_montgomery(curve, x).hex() == rec["from_montgomery"]
             n += 1
     assert n >= 10
+
+
+def test_the_collective_stand_in_exports_what_dist_hip_resolves():
+    """tests/host/fake_rccl.c builds and exports the seven entry points csrc/dist.hip resolves with dlsym (no GPU call is made here)."""
+    import ctypes
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src, out = os.path.join(root, "tests", "host", "fake_rccl.c"), os.path.join(root, "tests", "host", "libfake_rccl.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-lpthread"])
+    L = ctypes.CDLL(out)
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclCommAbort", "ncclCommCount", "ncclGetErrorString"):
+        assert hasattr(L, name), name
+    L.ncclGetErrorString.restype = ctypes.c_char_p
+    assert b"fake_rccl" in L.ncclGetErrorString(6)

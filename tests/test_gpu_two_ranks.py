@@ -82,3 +82,24 @@ def test_a_rank_that_never_enters_the_exchange():
     for r in res:
         assert r["ok"], r
     assert len({r["digest"] for r in res}) == 1 and res[0]["digest"]
+
+
+def test_bench_gpus_2_takes_the_c_abi_exchange_on_one_gpu():
+    """`python bench.py --gpus 2` end to end through csrc/dist.hip with two ranks: bench.py starts its ranks itself (the parent never
+    touches torch or HIP), the ranks share GPU 0 (MSM_BENCH_BACKEND=gloo carries the id, the barrier and the MAX over ranks), the engine's
+    own communicator is the shared-memory stand-in (MSM_AMD_RCCL_LIB) -- the driver's N > 1 flow, minus xGMI.  The line must say that
+    the C-ABI exchange ran with two ranks, and the result must be the one-GPU run's."""
+    lib = build_fake_rccl()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MSM_BENCH_BACKEND="gloo", MSM_AMD_RCCL_LIB=lib)
+    args = ["--steps", "6", "--warmup", "2", "--logn", "16", "--no-cpu-baseline"]
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + args, env=env, capture_output=True, text=True, timeout=600)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    two = json.loads(p2.stdout.strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["config"]["exchange"].startswith("C ABI") and two["config"]["rccl_ranks"] == 2, two["config"]
+    assert two["config"]["split"]["gp"] * two["config"]["split"]["gw"] == 2
+    env1 = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env1, capture_output=True, text=True, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = json.loads(p1.stdout.strip().splitlines()[-1])
+    assert one["result_x_prefix"] == two["result_x_prefix"]
