@@ -97,23 +97,24 @@ int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
 // alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
 // kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
 // many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
-// tools/shard_table.py, profiles/r03_shard_per_rank_table.txt; cells the sweep does not visit are geometric means of their neighbours).
+// tools/shard_table.py, profiles/r04_shard_per_rank_table.txt -- re-measured in round 4 with the work list on; tools/fit_share_tables.py: cells the
+// sweep does not visit keep the round-3 value scaled by the nearest re-measured cell).
 // Other curves and groups scale the table; the choice of a split only needs its shape.
 static const float kShareMsG1[14][4] = {
-    {0.409f, 0.420f, 0.360f, 0.400f},       // 2^13
-    {0.468f, 0.422f, 0.358f, 0.400f},       // 2^14
-    {0.456f, 0.436f, 0.358f, 0.400f},       // 2^15
-    {0.537f, 0.493f, 0.385f, 0.407f},       // 2^16
-    {0.667f, 0.564f, 0.431f, 0.450f},       // 2^17
-    {1.018f, 0.646f, 0.494f, 0.507f},       // 2^18
-    {1.638f, 0.849f, 0.618f, 0.600f},       // 2^19
-    {2.642f, 1.502f, 0.890f, 0.720f},       // 2^20
-    {5.359f, 3.032f, 1.615f, 1.160f},       // 2^21
-    {11.084f, 5.868f, 3.367f, 1.853f},      // 2^22
-    {20.108f, 10.494f, 6.534f, 3.470f},     // 2^23
-    {38.002f, 20.000f, 11.852f, 6.484f},    // 2^24
-    {71.697f, 39.131f, 23.514f, 12.460f},   // 2^25
-    {139.552f, 76.830f, 46.491f, 23.944f},  // 2^26
+    {0.399f, 0.410f, 0.351f, 0.390f},   // 2^13  (partly scaled from the G1 table)
+    {0.443f, 0.432f, 0.367f, 0.410f},   // 2^14  (partly scaled from the G1 table)
+    {0.405f, 0.445f, 0.367f, 0.410f},   // 2^15  (partly scaled from the G1 table)
+    {0.478f, 0.480f, 0.388f, 0.426f},   // 2^16
+    {0.646f, 0.521f, 0.411f, 0.429f},   // 2^17  (partly scaled from the G1 table)
+    {0.941f, 0.654f, 0.455f, 0.474f},   // 2^18
+    {1.612f, 0.897f, 0.581f, 0.564f},   // 2^19  (partly scaled from the G1 table)
+    {2.621f, 1.477f, 0.870f, 0.750f},   // 2^20
+    {5.182f, 2.919f, 1.528f, 1.098f},   // 2^21  (partly scaled from the G1 table)
+    {10.783f, 6.210f, 3.081f, 1.884f},   // 2^22
+    {19.352f, 10.017f, 6.281f, 3.335f},   // 2^23  (partly scaled from the G1 table)
+    {36.313f, 19.102f, 12.057f, 6.434f},   // 2^24
+    {69.476f, 37.931f, 23.844f, 12.635f},   // 2^25  (partly scaled from the G1 table)
+    {134.995f, 74.916f, 45.646f, 24.207f},   // 2^26
 };
 // The same for BN254 G1 and for G2 (round 4; tools/shard_table.py --curve bn128 / --group 2, profiles/r04_shard_table_*.txt, built with
 // tools/fit_share_tables.py: a cell is the best of two, three and four calls in flight; cells the sweeps did not visit are the G1 table's
