@@ -239,3 +239,79 @@ def test_a_nearly_full_device_gives_enomem_or_the_right_bytes():
         with open(os.path.join(log, "r04_oom_child.txt"), "w") as f:
             f.write("\n".join(res["notes"]) + "\n")
     assert res["ok"], res
+
+
+def _seeds(default):
+    """the committed seed, plus any in MSM_TEST_EXTRA_SEEDS (comma-separated; soak runs)"""
+    extra = [int(x) for x in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if x.strip()]
+    return [default] + extra
+
+
+@pytest.mark.parametrize("seed", _seeds(20261005))
+def test_randomised_round4_configurations(orc, seed):
+    """50 seeded random combinations of what round 4 added or touched: the work list on / off / forced with random lane lengths, every
+    partition geometry with either tile size, wide and narrow windows, scalar sizes the window does or does not divide, uniform / full-width /
+    short / heavily repeated scalars (long and hot buckets: the inlined tail kernels), synchronous, two in flight, prepared tables and
+    hybrid shards summed on this GPU -- each against the oracle."""
+    import msm_amd
+    from msm_amd import dist as mdist
+    rnd = random.Random(seed)
+    eng = msm_amd.Engine(0)
+    try:
+        for it in range(50):
+            curve = rnd.choice(["bls12381", "bn128"])
+            group = 1 if rnd.random() < 0.75 else 2
+            n = rnd.choice([1, 5, 64, 300, 2049, 6000, 20000, 45000] if group == 1 else [1, 9, 130, 700, 3000])
+            ss = rnd.choice([32, 32, 32, 31, 16, 8, 33])
+            C = eng.curve(curve)
+            O = orc.Oracle(curve, group)
+            asz = C.affine_bytes(group)
+            bases, _ = gu.random_case(curve, group, f"gpu:rand4:{seed}:{it}", n)
+            raw = gu.stream(f"gpu:rand4:{seed}:{it}:s", n * ss)
+            kind = rnd.choice(["uniform", "uniform", "full", "short", "repeated"])
+            sc = bytearray(raw)
+            if kind == "full":
+                for i in range(n):
+                    sc[i * ss + ss - 1] |= 0x80
+            elif kind == "short":
+                for i in range(n):
+                    sc[i * ss + max(1, ss // 2):(i + 1) * ss] = bytes(ss - max(1, ss // 2))
+            elif kind == "repeated":
+                k = rnd.choice([1, 3, 17])
+                for i in range(n):
+                    if rnd.random() < 0.8:
+                        j = rnd.randrange(k)
+                        sc[i * ss:(i + 1) * ss] = raw[j * ss:(j + 1) * ss] if j < n else raw[:ss]
+            scalars = bytes(sc)
+            opts = {"items": rnd.choice([0, 1, 1, 2]), "items_t": rnd.choice([0, 0, 8, 9, 16, 40, 300]), "sort_geom": rnd.choice([0, 0, 1, 2, 3]),
+                    "tile_mode": rnd.choice([0, 1, 2, 2]), "sort_big": rnd.choice([0, 0, 1, 2]), "hot": rnd.choice([1, 1, 0])}
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            c = rnd.choice([0, 0, 4, 9, 11, 13, 14, 16, 18, 19, 20, 21])
+            eng.set_window_bits(c)
+            exp = gu.canon(curve, group, O.normalize(O.multiexp_affine(bases, scalars, ss, n)), O.zero())
+            mode = rnd.choice(["full", "full", "async2", "prepared", "hybrid"])
+            tag = (seed, it, curve, group, n, ss, kind, c, mode, opts)
+            if mode == "full":
+                got = C._multiexp(group, 0, bases, scalars, ss, n)
+            elif mode == "async2":
+                t1, t2 = C.multiexp_async(group, bases, scalars, ss, n), C.multiexp_async(group, bases, scalars, ss, n)
+                got = t1.wait()
+                assert t2.wait() == got, tag
+            elif mode == "prepared":
+                pb = C.prepare_bases(group, bases, n, scalar_bits=rnd.choice([8 * ss, min(8 * ss + 5, 512)]))
+                try:
+                    got = pb.multiexp(scalars, ss, n)
+                finally:
+                    pb.release()
+            else:
+                world = rnd.choice([2, 3, 4, 8])
+                gw = rnd.choice([w for w in range(1, world + 1) if world % w == 0])
+                parts = []
+                for r in range(world):
+                    first, count = mdist.slice_of(n, world // gw, r // gw)
+                    parts.append(C.multiexp_shard(group, bases[first * asz:(first + count) * asz], scalars[first * ss:(first + count) * ss], ss, count, r % gw, gw))
+                got = msm_amd.combine(curve, group, b"".join(parts))
+            assert got == exp, (tag, eng.geometry(), eng.hints())
+    finally:
+        eng.close()
