@@ -129,7 +129,7 @@ def test_work_list_in_sharded_and_prepared_calls(orc):
     ("bls12381", 1, 60000, 20, {"tile_mode": 2, "sort_geom": 1}),     # the round-3 geometry stays selectable
 ])
 def test_partition_geometries_of_round_4(orc, curve, group, n, c, opts):
-    """The bucket sort's new shapes (csrc/engine.hip MsmCall::sort, csrc/sort_kernels.hpp): spans of up to 36864 entries read once by a
+    """The bucket sort's new shapes (csrc/engine_call.hpp MsmCall::sort, csrc/sort_kernels.hpp): spans of up to 36864 entries read once by a
     1024-lane workgroup, 512 coarse bins cut from tiles of 8192 scalars (13-bit ranks), the chunk-parallel kernels on 512 bins --
     forced at sizes the oracle can follow (`tile_mode` = 2: the wide tiles these shapes belong to; `sort_geom`), synchronous and two
     calls in flight, on caller-supplied bases and on a prepared table (merged windows: index slices over rows of 8192-padded stride)."""
