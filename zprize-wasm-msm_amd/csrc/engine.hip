@@ -166,10 +166,10 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
         (void)hipSetDevice(ctx->device);
         (void)hipEventSynchronize(found->ev[7]);
     }
-    int rc;
+    // the host combine runs outside the lock (the slot stays this thread's while `collecting` is set); only the bookkeeping is locked
+    const int rc = found->finish(ctx, found, out);
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
-        rc = found->finish(ctx, found, out);
         if (found->prepared) {
             found->prepared->in_flight.fetch_sub(1);
             found->prepared = nullptr;

@@ -908,15 +908,20 @@ template <class F>
 static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     using X = XYZZ<F>;
     const size_t XSZ = sizeof(X);
-    for (float& t : ctx->timings) t = 0.f;
+    // Runs WITHOUT the context's lock (round 4: the slot is this thread's while `collecting` is set; the host combine of one call no
+    // longer keeps other threads from submitting or collecting theirs -- the libuv workers behind concurrent JS promises).  What the
+    // context publishes about its last call -- timings, geometry -- is gathered in locals and copied under the lock at the end.
+    float tm[8] = {};
     const Geom& g = sl->g;
-    ctx->geometry[0] = g.c;
-    ctx->geometry[1] = g.W;
-    ctx->geometry[2] = g.half;
-    ctx->geometry[3] = g.Wl;
-    ctx->geometry[4] = ctx->geometry[5] = 0;
+    uint32_t geo[6] = {g.c, g.W, g.half, g.Wl, 0, 0};
+    auto publish = [&] {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        for (int i = 0; i < 8; ++i) ctx->timings[i] = tm[i];
+        for (int i = 0; i < 6; ++i) ctx->geometry[i] = geo[i];
+    };
     if (sl->trivial) {
         host_store_jacobian_normalised(XYZZ<typename HostOf<F>::type>::inf(), out);
+        publish();
         return 0;
     }
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -925,8 +930,8 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     uint32_t* h_tail = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(sl->h_partials) + (size_t)nparts * XSZ);
     {
         uint64_t entries = (uint64_t)h_tail[0] + h_tail[1];
-        ctx->geometry[4] = (uint32_t)entries;
-        ctx->geometry[5] = (uint32_t)(entries >> 32);
+        geo[4] = (uint32_t)entries;
+        geo[5] = (uint32_t)(entries >> 32);
         // Skewed input (buckets beyond the segment length: scalars wider than the group order, a hot bucket, adversarial data) usually
         // means long spans in the fine sort as well, which the sort only cuts into parallel chunks when it expects them: the next
         // calls of this context do (n = 2^20, 256-bit scalars: scatter stage 1.7 -> 0.3 ms from the second call on).
@@ -941,6 +946,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         if (g.merged && h_tail[6]) {
             msm_set_err(ctx, "a scalar has bits beyond the scalar_bits these bases were prepared for (msm_amd_prepare_bases): "
                              "the table holds no window for them; prepare with a larger scalar_bits or use msm_amd_multiexp");
+            publish();
             return MSM_AMD_EINVAL;
         }
     }
@@ -968,14 +974,15 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     auto t1 = std::chrono::steady_clock::now();
 
     float ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[7]); ctx->timings[0] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[1], sl->ev[2]); ctx->timings[1] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[2], sl->ev[3]); ctx->timings[2] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[3], sl->ev[4]); ctx->timings[3] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[9], sl->ev[5]); ctx->timings[4] = ms;
-    (void)hipEventElapsedTime(&ms, sl->ev[5], sl->ev[6]); ctx->timings[5] = ms;
-    ctx->timings[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
-    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]); ctx->timings[7] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[7]); tm[0] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[1], sl->ev[2]); tm[1] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[2], sl->ev[3]); tm[2] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[3], sl->ev[4]); tm[3] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[9], sl->ev[5]); tm[4] = ms;
+    (void)hipEventElapsedTime(&ms, sl->ev[5], sl->ev[6]); tm[5] = ms;
+    tm[6] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+    (void)hipEventElapsedTime(&ms, sl->ev[0], sl->ev[1]); tm[7] = ms;
+    publish();
     return 0;
 }
 

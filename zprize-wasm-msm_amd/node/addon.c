@@ -59,6 +59,7 @@ static int (*p_dist_destroy)(msm_amd_ctx *);
 static int (*p_multiexp_dist)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint8_t *);
 static int (*p_multiexp_dist_async)(msm_amd_ctx *, int, int, uint32_t, const void *, const void *, uint32_t, uint32_t, uint64_t *);
 static int (*p_dist_wait)(msm_amd_ctx *, int, int, uint64_t, uint8_t *);
+static int (*p_dist_comm_count)(const msm_amd_ctx *, int *, int *);
 
 static const char *load_engine(void) {
     if (g_lib) return NULL;
@@ -119,6 +120,7 @@ static const char *load_engine(void) {
     SYM(p_multiexp_dist, "msm_amd_multiexp_dist")
     SYM(p_multiexp_dist_async, "msm_amd_multiexp_dist_async")
     SYM(p_dist_wait, "msm_amd_dist_wait")
+    SYM(p_dist_comm_count, "msm_amd_dist_comm_count")
 #undef SYM
     return NULL;
 }
@@ -425,6 +427,30 @@ static napi_value js_dist_destroy(napi_env env, napi_callback_info info) {
     }
     p_dist_destroy((msm_amd_ctx *)ctx);
     return NULL;
+}
+/* distCommCount(ctx) -> {ranks, dead}: the ranks the group's communicator itself counts (ncclCommCount) and whether the group has been
+ * aborted (an exchange timed out or failed: every call of the group then rejects at once until distDestroy + distInit) */
+static napi_value js_dist_comm_count(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *ctx;
+    if (argc < 1 || napi_get_value_external(env, argv[0], &ctx) != napi_ok) {
+        napi_throw_type_error(env, NULL, "distCommCount(ctx)");
+        return NULL;
+    }
+    int ranks = 0, dead = 0;
+    if (p_dist_comm_count((const msm_amd_ctx *)ctx, &ranks, &dead)) {
+        napi_throw_error(env, "MSM_AMD_EINVAL", "distCommCount: the context is not in a group");
+        return NULL;
+    }
+    napi_value obj, v;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_create_int32(env, ranks, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "ranks", v));
+    NAPI_OK(napi_get_boolean(env, dead != 0, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "dead", v));
+    return obj;
 }
 static napi_value js_multiexp_chunk_async(napi_env env, napi_callback_info info) { return js_multiexp_async_common(env, info, 1); }
 
@@ -1017,6 +1043,7 @@ static napi_value init(napi_env env, napi_value exports) {
         {"distUniqueId", NULL, js_dist_unique_id, NULL, NULL, NULL, napi_enumerable, NULL},
         {"distInit", NULL, js_dist_init, NULL, NULL, NULL, napi_enumerable, NULL},
         {"distDestroy", NULL, js_dist_destroy, NULL, NULL, NULL, napi_enumerable, NULL},
+        {"distCommCount", NULL, js_dist_comm_count, NULL, NULL, NULL, napi_enumerable, NULL},
         {"normalize", NULL, js_normalize, NULL, NULL, NULL, napi_enumerable, NULL},
         {"toAffine", NULL, js_to_affine, NULL, NULL, NULL, napi_enumerable, NULL},
         {"eq", NULL, js_eq, NULL, NULL, NULL, napi_enumerable, NULL},

@@ -221,7 +221,10 @@ function curve(curveName, opts) {
         ifft: async (buff) => native.fft(ctx, C.id, 0, 1, buff),
         batchApplyKey: async (buff, first, inc) => native.batchApplyKey(ctx, C.id, 0, 0, buff, first, inc),
     };
-    return { name: curveName, n8q: C.n8, n8r: 32, Fr, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c) };
+    return { name: curveName, n8q: C.n8, n8r: 32, Fr, G1: group(1), G2: group(2), setWindowBits: (c) => native.setWindowBits(ctx, c),
+        // {ranks, dead} of this process's multi-GPU group (msm_amd_dist_comm_count): the ranks the communicator itself counts, and whether an
+        // exchange has timed out or failed -- a dead group rejects every call at once until it is destroyed and initialised anew
+        distInfo: () => native.distCommCount(ctx) };
 }
 
 /** 128-byte id of a multi-GPU group: rank 0 creates it and hands it to the other processes (msm_amd_dist_unique_id) */

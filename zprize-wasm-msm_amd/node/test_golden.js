@@ -208,7 +208,9 @@ async function main() {
         const one = msm.curve("bls12381", { device: 0, maxSlice: 1500, dist: { rank: 0, world: 1, id: msm.distUniqueId() } });
         const viaDist = await one.G1.multiExpAffine(b, sc);
         if (Buffer.from(viaDist).toString("hex") !== canon(r.out_norm, 48, zeroHex)) throw new Error("multi-GPU form (world of one) differs");
-        checked += 2;
+        const info = one.distInfo();
+        if (info.ranks !== 1 || info.dead) throw new Error("distInfo: " + JSON.stringify(info));
+        checked += 3;
     }
     // FFTs (tests/golden/golden_fft.json), in place through the export-shaped surface
     if (!hostOnly) {
