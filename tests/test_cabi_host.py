@@ -106,3 +106,38 @@ def test_the_collective_stand_in_exports_what_dist_hip_resolves():
         assert hasattr(L, name), name
     L.ncclGetErrorString.restype = ctypes.c_char_p
     assert b"fake_rccl" in L.ncclGetErrorString(6)
+
+
+def test_the_build_guard_rejects_an_msm_kernel_with_a_large_private_segment(tmp_path):
+    """tools/check_code_objects.py, rule 3 (round 4): a kernel of the MSM path whose private segment exceeds MSM_SCRATCH_RESERVE fails the
+    build -- the HSA runtime would give its queue bytes x 64 x 8192 of scratch at the first dispatch and abort the process when a nearly
+    full device cannot hold it.  A toy code object with one such kernel (cross-compiled for gfx950, never run) is rejected; the same
+    kernel under a name the guard knows to be checked at run time (k_fft_*) passes; the shipped library passes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "check_code_objects.py")
+    csrc = os.path.join(root, "zprize-wasm-msm_amd", "csrc")
+    src = tmp_path / "toy.hip"
+    src.write_text('''
+#include <hip/hip_runtime.h>
+template <int W> __device__ void body(unsigned* out, unsigned n, unsigned sel) {
+    volatile unsigned buf[W];
+    for (int i = 0; i < W; ++i) buf[i] = i * sel + threadIdx.x;
+    unsigned acc = 0;
+    for (unsigned i = 0; i < n; ++i) acc += buf[(i * sel + acc) % W];
+    out[threadIdx.x] = acc;
+}
+extern "C" __global__ void KERNEL_NAME(unsigned* out, unsigned n, unsigned sel) { body<200>(out, n, sel); }
+extern "C" __global__ void k_scratch_reserve(unsigned* out, unsigned n, unsigned sel) { body<32>(out, n, sel); }
+''')
+    verdicts = {}
+    for name in ("k_some_msm_kernel", "k_fft_something"):
+        so = tmp_path / f"{name}.so"
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-fPIC", "-shared", f"-DKERNEL_NAME={name}", "-o", str(so), str(src)])
+        p = subprocess.run([sys.executable, tool, str(so), "--sources", csrc], capture_output=True, text=True)
+        verdicts[name] = (p.returncode, p.stderr)
+    assert verdicts["k_some_msm_kernel"][0] == 1 and "private segment" in verdicts["k_some_msm_kernel"][1]
+    assert verdicts["k_fft_something"][0] == 0, verdicts["k_fft_something"][1]
+    p = subprocess.run([sys.executable, tool, os.path.join(csrc, "libmsm_amd.so"), "--sources", csrc], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
