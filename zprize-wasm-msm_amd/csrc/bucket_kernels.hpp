@@ -1,7 +1,9 @@
-// bucket_kernels.hpp -- the two ALU-bound kernels of the engine (bucket accumulation, bucket
-// reduction) and their launchers.  Each coordinate field gets its own translation unit
-// (bucket_*.hip) so the heavy instantiations compile in parallel; engine.hip only sees the
-// launcher declarations.
+// bucket_kernels.hpp -- the ALU-bound kernels of the engine and their launchers: bucket accumulation (one lane per bucket; the work
+// list: lanes per bucket in proportion to its population; slices; the tail kernels for over-long buckets) and bucket reduction.
+// What they replace: the reference's table walk `T[d-1] += P_i` (wasmcurves/src/build_multiexp.js:186-233) and reduceTable (:373-461).
+// Each coordinate field gets its own translation units (bucket_*.hip) so the heavy instantiations compile in parallel; engine.hip
+// (engine_call.hpp) only sees the launcher declarations.  Every point addition in these kernels is expanded inline: no kernel of the
+// MSM path carries a private segment beyond a few spilled registers (see tadd below and csrc/engine_ctx.hpp "scratch").
 #pragma once
 #include "engine_common.hpp"
 #include "curve_u.hpp"

@@ -306,7 +306,10 @@ struct XYZZU {
         r.zzz = fstore<typename K::M>(fmul(fmul(a.zzz, b.zzz), PPP));
         return r;
     }
-    // out-of-line forms; operands by reference (two large by-value structs were seen to arrive corrupted in a callee)
+    // out-of-line forms; operands by reference (two large by-value structs were seen to arrive corrupted in a callee).
+    // Since round 4 no shipped kernel calls them (a call keeps three points in the caller's private segment, and the HSA runtime turns
+    // bytes of private segment into half a gigabyte of scratch per hardware queue: bucket_kernels.hpp, tadd); they remain for the
+    // reduction built without MSM_G2_REDUCE_INLINE (experiments) and for the host cross-checks.
     __host__ __device__ __noinline__ static void add_to(XYZZU& r, const XYZZU& a, const XYZZU& b) { r = add(a, b); }
     __host__ __device__ __noinline__ static void dbl_to(XYZZU& r, const XYZZU& a) { r = dbl(a); }
     MSM_HD static XYZZU add_ni(const XYZZU& a, const XYZZU& b) {
