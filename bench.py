@@ -46,7 +46,10 @@ def uniform_scalars_mod_r(n, seed, r=R_BLS):
     todo = np.arange(n)
     while todo.size:
         cand = rng.integers(0, 1 << 64, size=(todo.size, 4), dtype=np.uint64)
-        cand[:, 3] &= np.uint64((1 << (r.bit_length() - 192)) - 1)
+        bits = (r - 1).bit_length()
+        for i in range(4):
+            lb = min(64, max(0, bits - 64 * i))
+            cand[:, i] &= np.uint64((1 << lb) - 1) if lb < 64 else np.uint64((1 << 64) - 1)
         # lexicographic compare cand < r from the top limb
         lt = np.zeros(todo.size, dtype=bool)
         eq = np.ones(todo.size, dtype=bool)
@@ -150,6 +153,8 @@ def main():
     ap.add_argument("--resident-bases", action="store_true", help="with --host-buffers: keep the bases on the GPU, copy only the scalars")
     ap.add_argument("--depth", type=int, default=0, help="calls in flight when pipelined (default 2; 4 for more than four ranks)")
     ap.add_argument("--no-pipeline", action="store_true", help="one call at a time (latency) instead of two in flight (throughput)")
+    ap.add_argument("--scalar-bits", type=int, default=0, help="scalars of this many significant bits in their 32 bytes (uniform below 2^bits; default 0: uniform below the "
+                    "group order, the metric's workload) -- 128-bit challenges, 64-bit witness values: prints its own line")
     ap.add_argument("--prepared", action="store_true", help="the bases are PREPARED once outside the timed region (msm_amd_prepare_bases: the window table of a prover's "
                     "fixed SRS) and every step is msm_amd_multiexp_prepared; prints its own line -- the default line stays the general path (N = 1 only)")
     args = ap.parse_args()
@@ -230,7 +235,7 @@ def main():
     plan = eng.dist_plan(args.curve, g, 32, n, world, rank) if sharded else {"gp": 1, "gw": 1, "first": 0, "count": n}
     first, count = plan["first"], plan["count"]
     pts = C.gen_points(g, 0xC0FFEE02, count, first)
-    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02, R_ORDER[args.curve])[first:first + count]      # below the curve's own group order
+    sc_host = uniform_scalars_mod_r(n, 0xC0FFEE02, R_ORDER[args.curve] if not args.scalar_bits else (1 << args.scalar_bits))[first:first + count]      # below the curve's own group order
     d_scalars = torch.from_numpy(sc_host).to(dev)
     torch.cuda.synchronize()
 
@@ -476,11 +481,11 @@ def main():
         mads = MADS_PER_ADD.get((args.curve, g))
         out = {
             "metric": ("BLS12-381 G1 MSM throughput (scalar-point pairs/sec) at n=2^20" if (args.curve, g, args.logn) == ("bls12381", 1, 20)
-                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}") + (" -- PREPARED BASES (not the headline path)" if prep is not None else ""),
+                       else f"{args.curve} G{g} MSM throughput (scalar-point pairs/sec) at n=2^{args.logn}") + (" -- PREPARED BASES (not the headline path)" if prep is not None else "") + (f" -- {args.scalar_bits}-BIT SCALARS (not the headline workload)" if args.scalar_bits else ""),
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u32 limbs (381-bit Montgomery integers)" if args.curve == "bls12381" else "u32 limbs (254-bit Montgomery integers)",
-            "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in [0,r); " + ("inputs in HOST memory, copied over PCIe inside every call" if args.host_buffers else "inputs resident in HBM"),
+            "data": "synthetic: P_i = k_i*G (GPU-generated), scalars uniform in " + (f"[0,2^{args.scalar_bits}); " if args.scalar_bits else "[0,r); ") + ("inputs in HOST memory, copied over PCIe inside every call" if args.host_buffers else "inputs resident in HBM"),
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,

@@ -241,6 +241,77 @@ def test_a_nearly_full_device_gives_enomem_or_the_right_bytes():
     assert res["ok"], res
 
 
+def _narrow(raw, n, bits):
+    """n 32-byte scalars of `bits` significant bits (the top one set: the width is exact) from the bytes of `raw`"""
+    out = bytearray(raw[:32 * n])
+    for i in range(n):
+        nb = bits // 8
+        out[32 * i + nb + (1 if bits % 8 else 0):32 * i + 32] = bytes(32 - nb - (1 if bits % 8 else 0))
+        if bits % 8:
+            out[32 * i + nb] &= (1 << (bits % 8)) - 1
+        out[32 * i + (bits - 1) // 8] |= 1 << ((bits - 1) % 8)
+    return bytes(out)
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 30000), ("bn128", 1, 120000), ("bls12381", 2, 4000)])
+def test_windows_follow_the_observed_scalar_width(orc, curve, group, n):
+    """Scalars much narrower than their 32 bytes (128-bit challenges, 64-bit witness values, a width the window does not divide): the
+    histogram pass reports the widest scalar of every call, two narrow calls in a row switch the context's next calls to windows that tile
+    that width (fewer windows, no carry bucket: msm_amd_get_geometry shows it), and whatever comes next is still exact -- a few bits more
+    (overflow window), a full-width call (reported by the histogram pass, run again over the declared width when collected: the caller
+    only sees the right bytes), alternating widths (the hint never engages), asynchronous calls in flight, option "narrow" = 0."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, uniform = gu.random_case(curve, group, f"gpu:narrow:{curve}:{group}:{n}", n)
+        f = _f(C, group)
+
+        def check(sc, what):
+            assert f(bases, sc, 32, n) == O.normalize(O.multiexp_affine(bases, sc, 32, n)), what
+            return eng.geometry()["windows"], eng.hints()["narrow_bits"]
+
+        full_w, _ = check(uniform, "full width, fresh context")
+        for bits in (128, 64, 200, 13):
+            sc = _narrow(uniform, n, bits)
+            w1, h1 = check(sc, f"{bits} bits, first call")
+            w2, h2 = check(sc, f"{bits} bits, second call")
+            w3, h3 = check(sc, f"{bits} bits, third call")
+            assert h2 == (bits + 7) // 8 * 8 and w3 < full_w, (bits, w1, w2, w3, h1, h2, h3)
+            # three bits more than the hint: the overflow window takes them, exactly; the hint is dropped
+            w4, h4 = check(_narrow(uniform, n, min(bits + 3 + (8 - bits % 8) % 8, 250)), f"{bits} bits + a few")
+            assert h4 == 0 or h4 >= bits
+            check(sc, "narrow again")
+            check(sc, "narrow again")
+            # a full-width call on a context that expects narrow ones: run again inside the wait, right bytes, hint gone
+            assert eng.hints()["narrow_bits"] != 0
+            w5, h5 = check(uniform, f"full width after {bits}-bit calls")
+            assert h5 == 0 and w5 in (full_w, full_w - 1)      # (the re-run tiles the declared 256 bits: no overflow window)
+            # a hint that cost a second run blocks narrow layouts for the next 64 calls (a stream that mixes widths)
+            for k in range(3):
+                assert check(sc, f"narrow, blocked {k}")[1] == 0
+            eng.set_option("narrow", 1)                          # (forgets the block and what was observed)
+        # alternating widths never engage the hint
+        eng.set_option("narrow", 1)
+        sc = _narrow(uniform, n, 100)
+        for k in range(6):
+            w, h = check(sc if k % 2 else uniform, f"alternating {k}")
+            assert h == 0
+        # asynchronous: two narrow calls in flight planned on the hint, then a wide one queued behind a narrow one
+        check(sc, "narrow")
+        check(sc, "narrow")
+        exp_n, exp_u = O.normalize(O.multiexp_affine(bases, sc, 32, n)), O.normalize(O.multiexp_affine(bases, uniform, 32, n))
+        t1, t2 = C.multiexp_async(group, bases, sc, 32, n), C.multiexp_async(group, bases, uniform, 32, n)
+        assert t2.wait() == exp_u and t1.wait() == exp_n
+        eng.set_option("narrow", 0)
+        for _ in range(3):
+            w, h = check(sc, "adaptation off")
+            assert h == 0 and w == full_w
+    finally:
+        eng.close()
+
+
 def _seeds(default):
     """the committed seed, plus any in MSM_TEST_EXTRA_SEEDS (comma-separated; soak runs)"""
     extra = [int(x) for x in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if x.strip()]

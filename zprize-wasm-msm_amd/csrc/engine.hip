@@ -136,6 +136,9 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return rc;
     }
     sl->pending = true;
+    sl->retry_args = a;
+    sl->retry_curve = curve;
+    sl->retry_group = group;
     sl->prepared = a.prepared;
     if (a.prepared) a.prepared->in_flight.fetch_add(1);
     sl->sync_owned = wait_for_slot;
@@ -167,7 +170,16 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
         (void)hipEventSynchronize(found->ev[7]);
     }
     // the host combine runs outside the lock (the slot stays this thread's while `collecting` is set); only the bookkeeping is locked
-    const int rc = found->finish(ctx, found, out);
+    int rc = found->finish(ctx, found, out);
+    RunArgs again;
+    int again_curve = 0, again_group = 0;
+    const bool retry = rc == MSM_RETRY_FULL_WIDTH;
+    if (retry) {
+        again = found->retry_args;
+        again.full_width = true;
+        again_curve = found->retry_curve;
+        again_group = found->retry_group;
+    }
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         if (found->prepared) {
@@ -179,6 +191,13 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
         found->sync_owned = false;
     }
     ctx->cv.notify_all();
+    if (retry) {
+        // the call was planned for scalars narrower than it met (engine_call.hpp, narrow layout): once more, over the declared width --
+        // the caller's buffers are still valid (they must be until the ticket has been waited for), and a slot is free: this one
+        uint64_t t2 = 0;
+        rc = submit(ctx, again_curve, again_group, again, &t2, true);
+        if (rc == 0) rc = finish_ticket(ctx, t2, out);
+    }
     return rc;
 }
 
@@ -506,6 +525,13 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     }
     if (!strcmp(name, "items")) { ctx->items_mode = value > 2 ? 0 : (int)value; return 0; }   // the accumulation's work list: 0 = where a launch is short of filling the chip, 1 = wherever the populations allow, 2 = never
     if (!strcmp(name, "items_t")) { ctx->items_t = value; return 0; }                         // experiments: entries per lane of the work list (0 = chosen per launch)
+    if (!strcmp(name, "narrow")) {   // 0 = windows never adapt to the observed scalar width; setting it (to anything) forgets what has been observed
+        ctx->narrow_mode = value != 0;
+        ctx->narrow_bits.store(0);
+        ctx->narrow_run.store(0);
+        ctx->narrow_block.store(0);
+        return 0;
+    }
     if (!strcmp(name, "hot")) { ctx->no_hot = value == 0; return 0; }   // 0 = hot buckets take the ordinary segment path (before / after measurements)
     if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return 0; }
     if (!strcmp(name, "even_windows")) { ctx->even_windows = value != 0; return 0; }   // 0 = the round-2 layout (c-bit windows only); default 1
@@ -713,7 +739,7 @@ int msm_amd_get_hints(const msm_amd_ctx* ctx, uint32_t* out4) {
     out4[0] = (uint32_t)std::max(0, ctx->wide_hint.load());
     out4[1] = (uint32_t)std::max(0, ctx->skew_hint.load());
     out4[2] = ctx->nslots;
-    out4[3] = ctx->last_items_T;
+    out4[3] = ctx->last_items_T | ((uint32_t)std::max(0, ctx->narrow_bits.load()) << 16);
     return 0;
 }
 int msm_amd_get_geometry(const msm_amd_ctx* ctx, uint32_t* out6) {

@@ -10,6 +10,8 @@
 #include "engine_ctx.hpp"
 #include "sort_kernels.hpp"
 
+constexpr int MSM_RETRY_FULL_WIDTH = 1;   // finish_msm -> finish_ticket: run the call again over the declared scalar width (never leaves the library)
+
 // (defined in engine.hip, used by plan(): a stream created late gets its scratch like the others)
 __global__ void k_scratch_reserve(uint32_t* out, uint32_t n, uint32_t sel);
 
@@ -145,15 +147,6 @@ static uint32_t pick_window_bits(uint32_t n, uint32_t nbits, uint32_t forced, ui
     return c;
 }
 
-struct RunArgs {
-    const void* bases;
-    const void* scalars;
-    uint32_t scalar_size, n, flags;
-    uint32_t bit_lo, nbits;   // scalar bit range
-    uint32_t shard, nshards;
-    bool raw_out;             // un-normalised Jacobian partial (multi-GPU shard)
-    msm_amd_bases* prepared = nullptr;   // bases = the handle's window table (msm_amd_multiexp_prepared)
-};
 
 template <class F>
 static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out);
@@ -285,6 +278,7 @@ int MsmCall<F>::plan() {
     g.ns = g.W;
     g.merged = 0;
     g.stride = 0;
+    g.check_wide = 0;
     // Windows of even width.  With nbits / c + 1 windows of c bits the top one holds nbits % c bits: when that is neither 0 nor the full
     // width, its 2^(nbits % c) buckets are 2^(c - 1 - nbits % c) times as dense as all the others (c = 13 over 256 bits: 256 buckets of
     // n / 256 entries each) and their lanes set the duration of the accumulation -- which is why round 2 found no window size between
@@ -301,14 +295,38 @@ int MsmCall<F>::plan() {
     // bits: with c-bit windows they also carry out of the top one into the carry-only window, whose single bucket then holds n / 2
     // entries -- 4.7 instead of 2.8 ms per MSM at n = 2^20; 1 signed + 16 unsigned 15-bit windows have no such window, for 6 % more
     // additions).  The hint decays over 16 calls without such entries being observable (the wide layout has no overflow window).
-    const bool wide = ctx->wide_hint.load() > 0 && a.nshards == 1 && !ctx->force_seg;
-    const uint32_t expected = (a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && !wide) ? OrderBits<F>::value : a.nbits;
+    const bool wide = (ctx->wide_hint.load() > 0 || a.full_width) && a.nshards == 1 && !ctx->force_seg;
+    // Scalars much NARROWER than their 32 bytes (round 4) -- 128-bit challenges, 64-bit witness values: in the layouts above half of
+    // them carry out of their top window into ONE bucket of the next (n / 2 entries: 2.3 instead of 1.4 ms per MSM at n = 2^20 for 128-bit
+    // scalars), and a width that is not a multiple of c leaves a top window of a few very dense buckets (200 bits: 5.1 ms against the
+    // 2.7 of full-width scalars).  k_tile_hist reports the widest scalar of every call; once two calls in a row were narrow the
+    // context's next calls tile THAT width (rounded up to a byte) with the same windows of even width, unsigned at the top, so that
+    // nothing carries out.  Safe whatever comes: up to c - 1 bits beyond the hint land in the overflow window (exact); a scalar beyond
+    // that is reported by the histogram pass (Geom::check_wide) and the call is run again over the declared width when it is
+    // collected (finish_ticket) -- one call pays twice, the hint is dropped.  Option "narrow" = 0 switches the adaptation off.
+    uint32_t narrow = 0;
+    if (!wide && !a.full_width && ctx->narrow_mode && a.nshards == 1 && !a.prepared && !ctx->force_seg && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) {
+        narrow = ctx->narrow_block.load() > 0 ? 0u : (uint32_t)std::max(0, ctx->narrow_bits.load());   // (blocked for 64 calls after a hint that cost a second run)
+        if (narrow + g.c > OrderBits<F>::value) narrow = 0;   // (less than a window to save)
+    }
+    const uint32_t expected = narrow ? std::max(narrow, 8u) : ((a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && !wide) ? OrderBits<F>::value : a.nbits);
     sl->top_is_overflow = false;
+    sl->narrow_layout = narrow != 0;
+    g.check_wide = narrow != 0;
+    if (narrow) {
+        // windows of c and c - 1 bits tile `expected` bits exactly, with an unsigned one at the top, only if W (c - 1) <= expected for
+        // W = expected / c + 1 -- always true at 255 bits, not for a narrow width (64 bits at c = 16: five 15-bit windows are 75 bits, the
+        // top one would hold 4 bits in 16 very dense buckets): take the widest window at or below the size's that does tile it
+        uint32_t cc = g.c;
+        while (cc > 3 && (expected / cc + 1) * (cc - 1) > expected) --cc;
+        g.c = cc;
+        g.half = 1u << (g.c - 1);
+    }
     // (c-bit windows that divide the declared width keep the old layout while its top real window is at least half used by scalars of the
     // expected width -- BLS12-381 at c = 16: 15 of 16 bits, signed: all 2^15 buckets; BN254 at c = 16 has 14 bits there, half the buckets
     // twice as dense, and takes the even layout: 14 windows of 16 bits, 2 of 15)
     const bool top_thin = g.nbits % g.c == 0 && expected < g.nbits && expected % g.c != 0 && expected % g.c < g.c - 1;
-    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide || top_thin)) {
+    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide || top_thin || narrow)) {
         g.W = (expected + g.c) / g.c;
         g.ns = expected > g.W * (g.c - 1) ? expected - g.W * (g.c - 1) : 0u;
         if (expected < g.nbits) {   // the overflow window: c - 1 bits from bit `expected` on cover the rest (nbits - expected <= 2 <= c - 1)
@@ -322,6 +340,7 @@ int MsmCall<F>::plan() {
         g.W = a.prepared->W;
         g.ns = a.prepared->ns;
         g.merged = 1;
+        g.check_wide = 1;
         g.stride = a.prepared->stride;
     }
     // GLV path -- only for callers that vouch for their bases (flag MSM_AMD_BASES_IN_SUBGROUP, or option "glv" = 2): k*P = k1*P + k2*phi(P)
@@ -335,7 +354,7 @@ int MsmCall<F>::plan() {
     // forces the path (tests, experiments).
     use_glv = false;
     if constexpr (GlvField<F>::value)
-        use_glv = !a.prepared && (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
+        use_glv = !narrow && !a.prepared && (ctx->glv_mode == 2 || (ctx->glv_mode == 1 && (a.flags & MSM_AMD_BASES_IN_SUBGROUP))) && g.c == 16 && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && a.n >= 1024 &&
                   (a.n <= (1u << 18) || ctx->glv_mode == 2) && a.n <= (1u << 26) && (((uintptr_t)d_scalars & 15) == 0);
     nv = use_glv ? 2 * a.n : a.n;   // items the sort and the accumulation see
     if (use_glv) {
@@ -894,7 +913,7 @@ int MsmCall<F>::reduce() {
     // calls that the input is skewed; scalars wider than a prepared table's windows; where the top owned window's entries start
     k_collect_tail<<<1, 64, 0, sb>>>(offset, count, NB, (g.Wl - 1) * g.half, (const uint32_t*)sl->d_tailctl.p, (const uint32_t*)sl->d_flags.p,
                                      reinterpret_cast<uint32_t*>(partials + (size_t)nparts * XSZ));
-    if (!ctx->zero_copy) HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ + 32, hipMemcpyDeviceToHost, sb));
+    if (!ctx->zero_copy) HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ + 48, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
     const uint32_t wgs_per_window = p0.wgs;
     sl->wgs_per_window = wgs_per_window;
@@ -940,8 +959,39 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         else if (ctx->skew_hint.load() > 0) ctx->skew_hint.fetch_sub(1);
         // entries in the overflow window (plan()): the scalars are wider than the group order -- the next calls tile the declared width
         if (g.nshards == 1 && !g.merged) {
-            if (sl->top_is_overflow && entries > (uint64_t)h_tail[7]) ctx->wide_hint.store(16);
-            else if (ctx->wide_hint.load() > 0) ctx->wide_hint.fetch_sub(1);
+            const bool over = sl->top_is_overflow && entries > (uint64_t)h_tail[7];   // entries in the overflow window
+            if (sl->narrow_layout) {
+                if (h_tail[6]) {   // a scalar beyond the narrow layout's windows: nothing of this run is usable -- the collector runs the call again
+                    ctx->narrow_bits.store(0);
+                    ctx->narrow_run.store(0);
+                    ctx->narrow_block.store(64);   // a stream that mixes widths: no narrow layouts for a while (a wrong hint costs a whole call)
+                    publish();
+                    return MSM_RETRY_FULL_WIDTH;
+                }
+                if (over) {   // a little wider than the hint (handled exactly by the overflow window): back to the default layout
+                    ctx->narrow_bits.store(0);
+                    ctx->narrow_run.store(0);
+                }
+            } else {
+                if (over) ctx->wide_hint.store(16);
+                else if (ctx->wide_hint.load() > 0) ctx->wide_hint.fetch_sub(1);
+            }
+            // the widest scalar of this call (k_tile_hist; 32-byte scalars read from registers only): two narrow calls in a row start a run
+            const uint32_t ob = h_tail[8];
+            if (ctx->narrow_block.load() > 0) ctx->narrow_block.fetch_sub(1);   // (nothing is learnt while blocked: a run starts afresh afterwards)
+            else if (ob && ctx->narrow_mode && g.scalar_size == 32 && g.bit_lo == 0) {
+                const uint32_t cand = (ob + 7u) & ~7u;
+                if (cand + g.c <= OrderBits<F>::value) {
+                    const int run = ctx->narrow_run.fetch_add(1) + 1;
+                    const int prev = ctx->narrow_cand.load();
+                    const int now = run == 1 ? (int)cand : std::max(prev, (int)cand);
+                    ctx->narrow_cand.store(now);
+                    if (run >= 2) ctx->narrow_bits.store(now);
+                } else {
+                    ctx->narrow_run.store(0);
+                    ctx->narrow_bits.store(0);
+                }
+            }
         }
         if (g.merged && h_tail[6]) {
             msm_set_err(ctx, "a scalar has bits beyond the scalar_bits these bases were prepared for (msm_amd_prepare_bases): "

@@ -74,6 +74,7 @@ struct Geom {
     // the rest c - 1 bits wide and unsigned (digit + carry in [0, 2^(c-1)], no carry out -- so the top window never spills into a
     // further one).  Calls on caller-supplied bases have merged = 0 and ns = W: every window c bits, signed.
     uint32_t merged, ns, stride;
+    uint32_t check_wide;    // 1: the windows cover less than the declared scalar width (a prepared table; the narrow layout of engine_call.hpp): scalar bits beyond them are REPORTED (flag word 0), never dropped silently
 };
 // first scalar bit of window w
 MSM_HD uint32_t window_start_bit(const Geom& g, uint32_t w) { return w <= g.ns ? w * g.c : g.ns * g.c + (w - g.ns) * (g.c - 1u); }

@@ -53,6 +53,18 @@ struct ZeroMark {
 
 using namespace msm;
 
+// One submission as the entry points describe it (engine.hip) and the call's stages read it (engine_call.hpp).
+struct RunArgs {
+    const void* bases;
+    const void* scalars;
+    uint32_t scalar_size, n, flags;
+    uint32_t bit_lo, nbits;   // scalar bit range
+    uint32_t shard, nshards;
+    bool raw_out;             // un-normalised Jacobian partial (multi-GPU shard)
+    msm_amd_bases* prepared = nullptr;   // bases = the handle's window table (msm_amd_multiexp_prepared)
+    bool full_width = false;             // the retry of a call whose narrow layout met a wider scalar: tile the declared width, ignore the hints
+};
+
 // One in-flight MSM: its scratch buffers, events and what the host needs to finish it.  A context owns
 // two slots so that the bucket reduction of one call (latency-bound, one wave per SIMD, stream B) overlaps
 // the sort + accumulation of the next call (throughput-bound, stream A).
@@ -77,10 +89,13 @@ struct Slot {
     Geom g{};
     uint32_t wgs_per_window = 0, nparts = 0, NB = 0;
     bool raw_out = false;
+    bool narrow_layout = false;     // the windows tile a width narrower than the declared one (the context's narrow hint): scalars beyond them make the collector run the call again
     bool top_is_overflow = false;   // the top owned window only holds what lies beyond the expected scalar width (plan(): empty for scalars below the group order)
     msm_amd_bases* prepared = nullptr;   // the call runs on a prepared table (released from in_flight when collected)
     DevBuf d_flags;                      // word 0: a scalar had bits beyond the windows of the prepared table
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
+    RunArgs retry_args{};            // what was submitted, kept so that the collector can run the call again (narrow layout met a wide scalar)
+    int retry_curve = 0, retry_group = 0;
     DevBuf* bufs[26] = {&d_itab, &d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
@@ -188,6 +203,10 @@ struct msm_amd_ctx {
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int reduce_pair = 0;    // option "reduce_pair" = 1: G1 bucket reduction with every point on a lane pair (measured: no gain)
     std::atomic<int> wide_hint{0};   // > 0: recent calls had scalars beyond the group order's bit length (entries in the overflow window): windows tile the declared width
+    // observed scalar width (engine_call.hpp plan()): narrow_bits > 0 = the width the next calls' windows tile; narrow_run = narrow calls in a row;
+    // narrow_cand = the widest of that run
+    std::atomic<int> narrow_bits{0}, narrow_run{0}, narrow_cand{0}, narrow_block{0};   // narrow_block: calls left during which no narrow layout is used (after a wrong hint)
+    int narrow_mode = 1;    // option "narrow": 0 = never adapt the windows to the observed scalar width
     std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
     std::atomic<size_t> scratch_level[2] = {};   // bytes per lane of private segment that streams A / S are known to hold scratch for (msm_scratch_guard)

@@ -146,6 +146,7 @@ __global__ void k_collect_tail(const uint32_t* __restrict__ offset, const uint32
         out[5] = tailctl[3];
         out[6] = flags[0];
         out[7] = offset[top_first];
+        out[8] = flags[1];   // significant bits of the widest scalar (k_tile_hist; 0 = not measured)
     }
 }
 
@@ -229,6 +230,22 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
     __syncthreads();
     DigitSource<NW, ITEMS, BLOCK> ds;
     ds.load(scalars, g, tile * (ITEMS * BLOCK));
+    if constexpr (NW == 8) {
+        // the widest scalar of the call (significant bits), for the planner of the context's NEXT calls: scalars much narrower than their
+        // 32 bytes -- 128-bit challenges, 64-bit witness values -- are better served by windows that tile the width they use (engine_call.hpp)
+        uint32_t mb = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; ++k) {
+            uint32_t top = 0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (ds.w[k][q]) top = 32u * q + 32u - (uint32_t)__clz(ds.w[k][q]);
+            mb = max(mb, top);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d, 64));
+        if ((threadIdx.x & 63u) == 0 && mb) atomicMax(too_wide + 1, mb);
+    }
     for (uint32_t w = 0; w < g.W; ++w) {
         const bool owned = g.merged || (w % g.nshards) == g.shard;
         const uint32_t wl = g.merged ? w : w / g.nshards;
@@ -240,7 +257,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
             if (owned && mag != 0) atomicAdd(&h[wl * sg.cb + ((mag - 1) >> sg.fbits)], 1u);
         }
     }
-    if (g.merged) {   // (uniform) scalar bits the table has no window for
+    if (g.check_wide) {   // (uniform) scalar bits the windows do not cover: a prepared table's, or the narrow layout's
         bool wide = false;
 #pragma unroll
         for (int k = 0; k < ITEMS; ++k) wide |= ds.leftover(scalars, g, k);
