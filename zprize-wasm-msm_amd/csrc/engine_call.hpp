@@ -299,15 +299,16 @@ int MsmCall<F>::plan() {
     // Scalars much NARROWER than their 32 bytes (round 4) -- 128-bit challenges, 64-bit witness values: in the layouts above half of
     // them carry out of their top window into ONE bucket of the next (n / 2 entries: 2.3 instead of 1.4 ms per MSM at n = 2^20 for 128-bit
     // scalars), and a width that is not a multiple of c leaves a top window of a few very dense buckets (200 bits: 5.1 ms against the
-    // 2.7 of full-width scalars).  k_tile_hist reports the widest scalar of every call; once two calls in a row were narrow the
-    // context's next calls tile THAT width (rounded up to a byte) with the same windows of even width, unsigned at the top, so that
+    // 2.7 of full-width scalars).  k_tile_hist reports the widest scalar of every call; once two calls in a row were narrower than the
+    // group order the context's next calls tile THAT width with the same windows of even width, unsigned at the top, so that
     // nothing carries out.  Safe whatever comes: up to c - 1 bits beyond the hint land in the overflow window (exact); a scalar beyond
     // that is reported by the histogram pass (Geom::check_wide) and the call is run again over the declared width when it is
     // collected (finish_ticket) -- one call pays twice, the hint is dropped.  Option "narrow" = 0 switches the adaptation off.
     uint32_t narrow = 0;
     if (!wide && !a.full_width && ctx->narrow_mode && a.nshards == 1 && !a.prepared && !ctx->force_seg && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) {
         narrow = ctx->narrow_block.load() > 0 ? 0u : (uint32_t)std::max(0, ctx->narrow_bits.load());   // (blocked for 64 calls after a hint that cost a second run)
-        if (narrow + g.c > OrderBits<F>::value) narrow = 0;   // (less than a window to save)
+        if (narrow >= OrderBits<F>::value) narrow = 0;
+        if (GlvField<F>::value && ctx->glv_mode == 2) narrow = 0;   // (the GLV schedule forced by option: its eight windows over the half scalars, whatever was observed)
     }
     const uint32_t expected = narrow ? std::max(narrow, 8u) : ((a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256 && !wide) ? OrderBits<F>::value : a.nbits);
     sl->top_is_overflow = false;
@@ -980,8 +981,10 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
             const uint32_t ob = h_tail[8];
             if (ctx->narrow_block.load() > 0) ctx->narrow_block.fetch_sub(1);   // (nothing is learnt while blocked: a run starts afresh afterwards)
             else if (ob && ctx->narrow_mode && g.scalar_size == 32 && g.bit_lo == 0) {
-                const uint32_t cand = (ob + 7u) & ~7u;
-                if (cand + g.c <= OrderBits<F>::value) {
+                // (any width below the group order's counts: even two bits less leave the top 16-bit window of a 255-bit layout a quarter used --
+                // 253-bit scalars ran 3.7 instead of 2.6 ms at n = 2^20.  No rounding: the overflow window takes up to c - 1 bits more, exactly.)
+                const uint32_t cand = ob;
+                if (cand < OrderBits<F>::value) {
                     const int run = ctx->narrow_run.fetch_add(1) + 1;
                     const int prev = ctx->narrow_cand.load();
                     const int now = run == 1 ? (int)cand : std::max(prev, (int)cand);
