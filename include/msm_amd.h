@@ -90,12 +90,13 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  *                    32-byte scalars are EXPECTED to use (the group order's: 255 / 254 bits) exactly, with one more window for the bits
  *                    above, which reduced scalars leave empty; scalars that do use those bits give the same result and switch the next
  *                    16 calls of the context to windows over all 256 bits.  0 = windows of c bits only (the round-2 layout)
- *   narrow           default 1: the windows follow the OBSERVED width of 32-byte scalars.  Every call reports its widest scalar; after two
- *                    narrow calls in a row (a window or more below the group order's width: 128-bit challenges, 64-bit values) the next calls'
- *                    windows tile that width -- fewer windows, nothing carried into a single bucket: 1.2 instead of 2.1 ms at n = 2^20 for
- *                    64-bit scalars.  Exact whatever follows: a few bits more land in an overflow window; a wider scalar is detected on the
- *                    GPU and the call is run again over the declared width inside its wait (that call pays twice, and narrow layouts stay
- *                    off for the next 64 calls).  0 = never; setting the option forgets what was observed
+ *   narrow           default 1: the windows follow the OBSERVED width of 32-byte scalars.  Every call reports its widest scalar; the maximum over
+ *                    the context's last eight calls, when below the group order's width (128-bit challenges, 64-bit values, a 253-bit field),
+ *                    is the width the next calls' windows tile -- fewer windows, nothing carried into a single bucket: 1.2 instead of 2.1 ms
+ *                    at n = 2^20 for 64-bit scalars.  Exact whatever follows: a few bits more land in an overflow window; a wider scalar is
+ *                    detected on the GPU and the call is run again over the declared width inside its wait (that one call pays twice; the
+ *                    hint follows from the next call on; streams that alternate widths keep the wide layout).  0 = never; setting the
+ *                    option forgets what was observed
  *   zero_copy        default 1: the window partials are written by the reduction kernel straight into pinned host memory
  *   dist_gw          window groups of a call of a multi-GPU group (0 = planned per call, else a divisor of the world size); must be the
  *                    same on every rank (checked in the exchange: MSM_AMD_EINVAL on every rank otherwise)

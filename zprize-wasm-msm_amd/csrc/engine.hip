@@ -527,9 +527,9 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
     if (!strcmp(name, "items_t")) { ctx->items_t = value; return 0; }                         // experiments: entries per lane of the work list (0 = chosen per launch)
     if (!strcmp(name, "narrow")) {   // 0 = windows never adapt to the observed scalar width; setting it (to anything) forgets what has been observed
         ctx->narrow_mode = value != 0;
+        std::lock_guard<std::mutex> hl(ctx->hint_mu);
         ctx->narrow_bits.store(0);
-        ctx->narrow_run.store(0);
-        ctx->narrow_block.store(0);
+        ctx->width_count = 0;
         return 0;
     }
     if (!strcmp(name, "hot")) { ctx->no_hot = value == 0; return 0; }   // 0 = hot buckets take the ordinary segment path (before / after measurements)

@@ -303,10 +303,11 @@ int MsmCall<F>::plan() {
     // group order the context's next calls tile THAT width with the same windows of even width, unsigned at the top, so that
     // nothing carries out.  Safe whatever comes: up to c - 1 bits beyond the hint land in the overflow window (exact); a scalar beyond
     // that is reported by the histogram pass (Geom::check_wide) and the call is run again over the declared width when it is
-    // collected (finish_ticket) -- one call pays twice, the hint is dropped.  Option "narrow" = 0 switches the adaptation off.
+    // collected (finish_ticket) -- one call pays twice; its width joins the last eight, whose maximum is the hint.  Option "narrow" = 0
+    // switches the adaptation off.
     uint32_t narrow = 0;
     if (!wide && !a.full_width && ctx->narrow_mode && a.nshards == 1 && !a.prepared && !ctx->force_seg && a.scalar_size == 32 && a.bit_lo == 0 && a.nbits == 256) {
-        narrow = ctx->narrow_block.load() > 0 ? 0u : (uint32_t)std::max(0, ctx->narrow_bits.load());   // (blocked for 64 calls after a hint that cost a second run)
+        narrow = (uint32_t)std::max(0, ctx->narrow_bits.load());
         if (narrow >= OrderBits<F>::value) narrow = 0;
         if (GlvField<F>::value && ctx->glv_mode == 2) narrow = 0;   // (the GLV schedule forced by option: its eight windows over the half scalars, whatever was observed)
     }
@@ -314,7 +315,13 @@ int MsmCall<F>::plan() {
     sl->top_is_overflow = false;
     sl->narrow_layout = narrow != 0;
     g.check_wide = narrow != 0;
-    if (narrow) {
+    // Which calls take windows of even width: those whose window size does not divide the width, and every call whose scalars are
+    // expected to FILL the width that is tiled (round 4) -- the observed width, the declared width of scalars that are not 32 bytes long
+    // or of a bit range, 256-bit scalars after a wide call: with c-bit windows over a width c divides, half of such scalars carry out
+    // of the top window into ONE bucket of a carry-only window (n / 2 entries; 16-byte scalars ran 3.05 ms at n = 2^20, 24-byte ones
+    // 4.6).  Only 32-byte scalars below the group order keep c-bit windows where c divides 256: their top bit is clear, nothing carries.
+    const bool fills = narrow != 0 || expected == g.nbits;
+    if (!a.prepared && ctx->even_windows && fills && g.nbits > g.c) {
         // windows of c and c - 1 bits tile `expected` bits exactly, with an unsigned one at the top, only if W (c - 1) <= expected for
         // W = expected / c + 1 -- always true at 255 bits, not for a narrow width (64 bits at c = 16: five 15-bit windows are 75 bits, the
         // top one would hold 4 bits in 16 very dense buckets): take the widest window at or below the size's that does tile it
@@ -323,11 +330,23 @@ int MsmCall<F>::plan() {
         g.c = cc;
         g.half = 1u << (g.c - 1);
     }
+    // A bit range no wider than the window (the reference's per-window entry point, fnName_chunk: what its external caller fans out): ONE
+    // unsigned window over 2^nbits buckets -- the signed form put half the scalars into the single bucket of a carry window
+    // (chunk(0, 16) at n = 2^20: 2.7 ms, an 8-bit chunk 6.6).
+    const bool one_window = !a.prepared && ctx->even_windows && g.nbits <= g.c && g.nbits >= 2 && g.nbits + 1 <= (uint32_t)MAX_WINDOW_BITS && !ctx->force_c;
+    if (one_window) {
+        g.c = g.nbits + 1;
+        g.half = 1u << (g.c - 1);
+        g.W = 1;
+        g.ns = 0;
+    }
     // (c-bit windows that divide the declared width keep the old layout while its top real window is at least half used by scalars of the
     // expected width -- BLS12-381 at c = 16: 15 of 16 bits, signed: all 2^15 buckets; BN254 at c = 16 has 14 bits there, half the buckets
     // twice as dense, and takes the even layout: 14 windows of 16 bits, 2 of 15)
     const bool top_thin = g.nbits % g.c == 0 && expected < g.nbits && expected % g.c != 0 && expected % g.c < g.c - 1;
-    if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide || top_thin || narrow)) {
+    if (one_window) {
+        // (laid out above: one unsigned window, no carry, no overflow window)
+    } else if (!a.prepared && ctx->even_windows && g.c >= 3 && g.nbits > g.c && (g.nbits % g.c != 0 || wide || top_thin || fills)) {
         g.W = (expected + g.c) / g.c;
         g.ns = expected > g.W * (g.c - 1) ? expected - g.W * (g.c - 1) : 0u;
         if (expected < g.nbits) {   // the overflow window: c - 1 bits from bit `expected` on cover the rest (nbits - expected <= 2 <= c - 1)
@@ -961,39 +980,25 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         // entries in the overflow window (plan()): the scalars are wider than the group order -- the next calls tile the declared width
         if (g.nshards == 1 && !g.merged) {
             const bool over = sl->top_is_overflow && entries > (uint64_t)h_tail[7];   // entries in the overflow window
+            // the widest scalar of this call (k_tile_hist; 32-byte scalars read from registers only) joins the last eight: their maximum is
+            // what the next calls' windows tile.  A stream that alternates widths therefore keeps the wide layout (no second runs), a
+            // stream that turns wider pays ONE second run and follows from the next call on, one that turns narrower follows eight calls later.
+            const uint32_t ob = h_tail[8];
+            if (ob && ctx->narrow_mode && g.scalar_size == 32 && g.bit_lo == 0) {
+                std::lock_guard<std::mutex> hl(ctx->hint_mu);
+                ctx->width_hist[ctx->width_count++ % 8u] = (uint16_t)ob;
+                uint32_t m = 0;
+                for (uint32_t i = 0; i < std::min(ctx->width_count, 8u); ++i) m = std::max<uint32_t>(m, ctx->width_hist[i]);
+                ctx->narrow_bits.store(ctx->width_count >= 2 ? (int)m : 0);
+            }
             if (sl->narrow_layout) {
                 if (h_tail[6]) {   // a scalar beyond the narrow layout's windows: nothing of this run is usable -- the collector runs the call again
-                    ctx->narrow_bits.store(0);
-                    ctx->narrow_run.store(0);
-                    ctx->narrow_block.store(64);   // a stream that mixes widths: no narrow layouts for a while (a wrong hint costs a whole call)
                     publish();
                     return MSM_RETRY_FULL_WIDTH;
-                }
-                if (over) {   // a little wider than the hint (handled exactly by the overflow window): back to the default layout
-                    ctx->narrow_bits.store(0);
-                    ctx->narrow_run.store(0);
                 }
             } else {
                 if (over) ctx->wide_hint.store(16);
                 else if (ctx->wide_hint.load() > 0) ctx->wide_hint.fetch_sub(1);
-            }
-            // the widest scalar of this call (k_tile_hist; 32-byte scalars read from registers only): two narrow calls in a row start a run
-            const uint32_t ob = h_tail[8];
-            if (ctx->narrow_block.load() > 0) ctx->narrow_block.fetch_sub(1);   // (nothing is learnt while blocked: a run starts afresh afterwards)
-            else if (ob && ctx->narrow_mode && g.scalar_size == 32 && g.bit_lo == 0) {
-                // (any width below the group order's counts: even two bits less leave the top 16-bit window of a 255-bit layout a quarter used --
-                // 253-bit scalars ran 3.7 instead of 2.6 ms at n = 2^20.  No rounding: the overflow window takes up to c - 1 bits more, exactly.)
-                const uint32_t cand = ob;
-                if (cand < OrderBits<F>::value) {
-                    const int run = ctx->narrow_run.fetch_add(1) + 1;
-                    const int prev = ctx->narrow_cand.load();
-                    const int now = run == 1 ? (int)cand : std::max(prev, (int)cand);
-                    ctx->narrow_cand.store(now);
-                    if (run >= 2) ctx->narrow_bits.store(now);
-                } else {
-                    ctx->narrow_run.store(0);
-                    ctx->narrow_bits.store(0);
-                }
             }
         }
         if (g.merged && h_tail[6]) {

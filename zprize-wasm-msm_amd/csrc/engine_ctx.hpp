@@ -203,9 +203,12 @@ struct msm_amd_ctx {
     int no_split = 1;       // option "split" = 1 splits a lone call into two window groups (measured slower: off by default)
     int reduce_pair = 0;    // option "reduce_pair" = 1: G1 bucket reduction with every point on a lane pair (measured: no gain)
     std::atomic<int> wide_hint{0};   // > 0: recent calls had scalars beyond the group order's bit length (entries in the overflow window): windows tile the declared width
-    // observed scalar width (engine_call.hpp plan()): narrow_bits > 0 = the width the next calls' windows tile; narrow_run = narrow calls in a row;
-    // narrow_cand = the widest of that run
-    std::atomic<int> narrow_bits{0}, narrow_run{0}, narrow_cand{0}, narrow_block{0};   // narrow_block: calls left during which no narrow layout is used (after a wrong hint)
+    // observed scalar width (engine_call.hpp plan()): the widest scalar of each of the last eight eligible calls; narrow_bits = their
+    // maximum once two have been seen (0 = nothing known): the width the next calls' windows tile when it is below the group order's
+    std::mutex hint_mu;
+    uint16_t width_hist[8] = {};
+    uint32_t width_count = 0;
+    std::atomic<int> narrow_bits{0};
     int narrow_mode = 1;    // option "narrow": 0 = never adapt the windows to the observed scalar width
     std::atomic<int> skew_hint{0};   // > 0: recent calls had buckets beyond the segment length; the sort then expects long spans
     int sort_big = 0;       // option "sort_big": 0 = chunk-parallel sort of long spans where they are expected, 1 = always, 2 = never (tests)
