@@ -489,6 +489,7 @@ def main():
             "config": {"workload": f"{args.curve} G{g} MSM n=2^{args.logn}, 32-byte scalars", "window_bits": geom["c"],
                        "windows": geom["windows"], "buckets_per_window": geom["buckets_per_window"],
                        "calls_in_flight": depth,
+                       "engine_options": args.opt or None,   # --opt NAME=VALUE given on the command line (experiments; none for the judged line)
                        "bases": ("caller-supplied per call (the reference's interface: msm_amd_multiexp)" if prep is None else
                                  {"form": "prepared once outside the timed region (msm_amd_prepare_bases); every step is msm_amd_multiexp_prepared",
                                   **prep.info(), "prepare_s": t_prep}),

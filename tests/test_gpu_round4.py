@@ -398,3 +398,49 @@ def test_randomised_round4_configurations(orc, seed):
             assert got == exp, (tag, eng.geometry(), eng.hints())
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("curve,group,n,c,rl", [
+    ("bls12381", 1, 4000, 9, 4),       # 256 buckets per window: one wave per window (no second stage)
+    ("bls12381", 1, 4000, 10, 4),      # two waves per window: the smallest second stage
+    ("bls12381", 1, 6000, 16, 2),      # 256 waves per window: every lane of the second stage adds four waves first, two upper planes
+    ("bls12381", 1, 6000, 16, 8),      # 64 waves per window: the second stage's wave exactly full
+    ("bls12381", 1, 6000, 16, 128),    # long running sums, four waves per window
+    ("bls12381", 1, 3000, 19, 32),     # 2^18 buckets per window
+    ("bn128", 1, 5000, 13, 4),
+    ("bn128", 1, 5000, 16, 2),
+    ("bls12381", 2, 2500, 12, 4),      # a point on a lane pair: 32 points per wave
+    ("bls12381", 2, 2500, 16, 16),     # ... 64 waves per window on a 32-lane second stage: two per lane, one upper plane
+    ("bn128", 2, 2500, 14, 8),
+])
+def test_reduction_as_plain_sums(orc, curve, group, n, c, rl):
+    """The bucket reduction without a scalar multiplication (k_bucket_planes / k_planes_combine, csrc/bucket_kernels.hpp: the window sum as
+    sum T_t + sum_b 2^(b + log2 L) P_b, the weights applied by the host's Horner pass) against the oracle, forced on at window sizes and
+    running-sum lengths that give one, two, a full wave of and four times a full wave of waves per window -- and the same calls through
+    k_bucket_reduce.  Reference semantics: wasmcurves/src/build_multiexp.js:186-233 (the window's bucket sum)."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_option("reduce_planes", 2)
+        eng.set_option("reduce_l", rl)
+        eng.set_window_bits(c)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        bases, scalars = gu.random_case(curve, group, f"gpu:planes:{curve}:{group}:{n}:{c}", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        assert _f(C, group)(bases, scalars, 32, n) == exp
+        t1, t2 = C.multiexp_async(group, bases, scalars, 32, n), C.multiexp_async(group, bases, scalars, 32, n)
+        assert t1.wait() == exp and t2.wait() == exp
+        # every scalar equal: one bucket per window holds everything, all other sums of the butterfly are infinity
+        same = scalars[:32] * n
+        exp_same = O.normalize(O.multiexp_affine(bases, same, 32, n))
+        assert _f(C, group)(bases, same, 32, n) == exp_same
+        # 64-bit values: the windows above them are empty (their partials are written as infinities by whichever stage runs last)
+        small = b"".join(scalars[i * 32:i * 32 + 8] + bytes(24) for i in range(n))
+        exp_small = O.normalize(O.multiexp_affine(bases, small, 32, n))
+        eng.set_option("narrow", 0)
+        assert _f(C, group)(bases, small, 32, n) == exp_small
+        eng.set_option("reduce_planes", 0)
+        assert _f(C, group)(bases, scalars, 32, n) == exp
+    finally:
+        eng.close()

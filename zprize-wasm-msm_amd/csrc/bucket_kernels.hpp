@@ -602,6 +602,168 @@ __global__ void __launch_bounds__(256) k_bucket_reduce(const uint8_t* __restrict
     if (lt == 0) sh[threadIdx.x].to_packed(reinterpret_cast<uint32_t*>(partials + (size_t)blockIdx.x * sizeof(XYZZ<F>)));
 }
 
+// ------------------------------------------------------------------------------------------
+// stage 5 without a scalar multiplication ("bit planes", round 4).  With lane t of a window owning the L buckets from t*L on,
+//     S_w = sum_t T_t + L * sum_t t * A_t          (T_t = sum_j (j+1) B[tL+j],  A_t = sum_j B[tL+j]: the running sums above)
+//         = sum_t T_t + sum_b 2^(b + log2 L) * P_b   with   P_b = sum of A_t over the lanes t whose bit b is set,
+// and the weights 2^(b + log2 L) cost nothing: the host's Horner pass over the windows doubles once per bit anyway and adds P_b when
+// it passes bit (window start + b + log2 L).  What is left on the GPU are PLAIN sums: k_bucket_reduce's per-lane double-and-add by
+// t*L (13 doublings + ~7 additions at L = 8: 45 % of its instructions and of its dependent chain) is gone.
+//
+// The unit of work is ONE WAVE -- no LDS, no barrier, nobody waits for anybody: a SIMD's multiplier is saturated by a single wave of
+// these additions, so what counts is that every resident wave is busy (in a 256-lane workgroup tree three of four waves idle at the
+// barrier and hold their registers; measured: 1.1 ms for the 2048 workgroups of n = 2^20 against 0.72 ms for k_bucket_reduce).
+// After the running sums the 2^k lanes of the wave (k = 6; 5 where a point takes a lane pair) hold A_t and T_t in registers, partners
+// are fetched with ds_bpermute, and ONE loop of k + 1 additions finishes both sums:
+//  * the planes come out of an in-place butterfly over X[lane] = A_t: step s (d = 2^(k-1-s)) folds X[e] += X[e+d] for e < d -- X[0]
+//    ends as the total -- while the upper halves X[d .. 2d) it leaves behind are exactly the summands of plane k-1-s and are summed in
+//    place by the following steps (X[d+e] += X[d+e+m], m = d/2, d/4, ...): P_b ends in lane 2^b;
+//  * the sum of T_t folds UPWARD (lane i += lane i - 2^(k-1-i')), one step ahead of the butterfly, so that its lanes (the top 2^(k-1-i'))
+//    never coincide with the butterfly's (below 2^(k-1) + d/2): it ends in the last lane.
+// A window of several waves is finished by k_planes_combine: one wave per (window, value).  2L + k + 1 additions per wave of 64 L
+// buckets -- 2.9 per bucket at L = 8 (k_bucket_reduce: 4.9), chain 23 + 7 instead of 45.
+// ------------------------------------------------------------------------------------------
+template <class P>
+MSM_D P lane_fetch(const P& p, uint32_t src_thread) {
+    constexpr int NW = sizeof(P) / 4;
+    static_assert(sizeof(P) % 4 == 0, "whole words");
+    struct Words {
+        uint32_t w[NW];
+    };
+    const Words s = __builtin_bit_cast(Words, p);
+    Words r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_thread * 4u), (int)s.w[i]);
+    return __builtin_bit_cast(P, r);
+}
+template <class P>
+MSM_D P lane_select(bool first, const P& a, const P& b) {
+    constexpr int NW = sizeof(P) / 4;
+    struct Words {
+        uint32_t w[NW];
+    };
+    const Words x = __builtin_bit_cast(Words, a), y = __builtin_bit_cast(Words, b);
+    Words r;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) r.w[i] = first ? x.w[i] : y.w[i];
+    return __builtin_bit_cast(P, r);
+}
+// butterfly step over 2^klog logical lanes, in place (the lane that holds X[dst] adds): the partner of lane lt at step s, or none
+MSM_D bool planes_partner(uint32_t lt, uint32_t klog, uint32_t s, bool trees, uint32_t* src) {
+    const uint32_t d = (1u << klog) >> (s + 1), m = d >> 1;
+    if (lt < d) {
+        *src = lt + d;
+        return true;
+    }
+    const uint32_t base = 1u << (31 - __clz(lt | 1u));   // the region [2^j, 2^(j+1)) lane lt lies in: the summands of plane j (j >= log2 d here)
+    *src = lt + m;
+    return trees && lt >= d && lt < (1u << klog) && lt - base < m;
+}
+template <class F>
+MSM_D bool planes_window_empty(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count, uint32_t gb, uint32_t half, uint32_t NB) {
+    const uint32_t beg = offset[gb];
+    const uint32_t end = gb + half < NB ? offset[gb + half] : offset[NB - 1] + count[NB - 1];
+    return beg == end;
+}
+// values a wave leaves for its window when the window has several: [0] sum of T_t, [1] total, [2+b] P_b of the local lane bit b
+template <class F>
+__global__ void __launch_bounds__(64) k_bucket_planes(const uint8_t* __restrict__ buckets, uint32_t half, uint32_t L, uint32_t wpw, uint8_t* __restrict__ wvout,
+                                                       uint8_t* __restrict__ partials, const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count,
+                                                       uint32_t gb0, uint32_t NB) {
+    constexpr uint32_t T = UKind<F>::type::LANES, LPW = 64u / T, KLOG = T == 1 ? 6u : 5u, NV = KLOG + 2u;
+    static_assert(T == 1 || T == 2, "a point on one lane or on a lane pair");
+    const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T;
+    const uint32_t w = blockIdx.x / wpw;
+    constexpr uint32_t np1 = 1 + KLOG;   // partials of a window that one wave covers
+    if (planes_window_empty<F>(offset, count, gb0 + w * half, half, NB)) {
+        // nothing was scattered into this window (the carry window above 255-bit scalars): every sum is infinity
+        if (wpw == 1 && lt < np1) BU<F>::inf().to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np1 + lt) * sizeof(XYZZ<F>)));
+        return;   // (several waves: k_planes_combine sees the same and writes the infinities)
+    }
+    const uint32_t base = ((blockIdx.x % wpw) * LPW + lt) * L;
+    BU<F> run = BU<F>::inf(), sum = BU<F>::inf();
+    for (int j = (int)L - 1; j >= 0; --j) {
+        const BU<F> bk = load16<BU<F>>(buckets + (((size_t)w * half + base + j) * T + sub) * sizeof(BU<F>));
+        run = radd<F>(run, bk);
+        sum = radd<F>(sum, run);
+    }
+    for (uint32_t i = 0; i <= KLOG; ++i) {
+        // the upward fold of the T_t (i < KLOG) and butterfly step i - 1 (i >= 1): disjoint lanes
+        const uint32_t h = LPW >> (i + 1);
+        const bool t_on = i < KLOG && lt >= LPW - h;
+        uint32_t a_src = lt;
+        const bool a_on = i >= 1 && planes_partner(lt, KLOG, i - 1, true, &a_src);
+        const BU<F> ft = lane_fetch(sum, ((lt - h) & (LPW - 1u)) * T + sub);
+        const BU<F> fa = lane_fetch(run, (a_src & (LPW - 1u)) * T + sub);
+        const BU<F> r = radd<F>(lane_select(t_on, sum, run), lane_select(t_on, ft, fa));
+        if (t_on) sum = r;
+        if (a_on) run = r;
+    }
+    // lane LPW-1: sum of T_t; lane 0: total; lane 2^b: P_b
+    if (wpw == 1) {
+        if (lt == LPW - 1) sum.to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np1) * sizeof(XYZZ<F>)));
+        if (lt != 0 && (lt & (lt - 1)) == 0 && lt != LPW - 1) run.to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np1 + 1 + (31 - __clz(lt))) * sizeof(XYZZ<F>)));
+    } else {
+        uint8_t* o = wvout + (size_t)blockIdx.x * NV * T * sizeof(BU<F>);
+        if (lt == LPW - 1) store16(o + sub * sizeof(BU<F>), sum);
+        if ((lt & (lt - 1)) == 0) store16(o + ((size_t)(lt == 0 ? 1u : 2u + (31 - __clz(lt))) * T + sub) * sizeof(BU<F>), run);
+    }
+}
+// The window's sums over its waves: one wave per (window, value) -- plain trees for the sum of T_t and the local planes, the butterfly
+// again over the waves' totals (planes of the bits above the local ones).  A window of more waves than a wave has lanes (up to four
+// times as many: qlog <= 2) gives every lane 2^qlog of them to add up first, wave q*LPW + lane for q = 0, 1, ...; the planes of the
+// bits of q are plain sums again -- of the totals of the waves whose q has the bit -- and get a wave of their own (v >= NV).
+// Partials of a window, in the order the host adds them: [0] weight 1, [1+b] weight 2^(b + log2 L), b < KLOG + mlog.
+template <class F>
+__global__ void __launch_bounds__(64) k_planes_combine(const uint8_t* __restrict__ wvout, uint32_t half, uint32_t mlog, uint8_t* __restrict__ partials,
+                                                        const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count, uint32_t gb0, uint32_t NB) {
+    constexpr uint32_t T = UKind<F>::type::LANES, LPW = 64u / T, KLOG = T == 1 ? 6u : 5u, NV = KLOG + 2u;
+    const uint32_t lt = threadIdx.x / T, sub = threadIdx.x % T, wpw = 1u << mlog;
+    const uint32_t tlog = min(mlog, KLOG), qlog = mlog - tlog;   // lanes of the tree, waves per lane
+    const uint32_t np = 1 + KLOG + mlog, nvq = NV + qlog;
+    const uint32_t w = blockIdx.x / nvq, v = blockIdx.x % nvq;
+    if (planes_window_empty<F>(offset, count, gb0 + w * half, half, NB)) {
+        if (v == 0 && lt < np) BU<F>::inf().to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np + lt) * sizeof(XYZZ<F>)));
+        return;
+    }
+    const uint32_t vv = v < NV ? v : 1u;   // the waves of the upper planes add totals
+    auto elem = [&](uint32_t q) { return load16<BU<F>>(wvout + ((((size_t)w * wpw + q * LPW + lt) * NV + vv) * T + sub) * sizeof(BU<F>)); };
+    BU<F> x = BU<F>::inf();
+    if (lt < (1u << tlog)) {
+        if (v < NV) {
+            x = elem(0);
+            for (uint32_t q = 1; q < (1u << qlog); ++q) x = radd<F>(x, elem(q));
+        } else {
+            for (uint32_t q = 1; q < (1u << qlog); ++q)
+                if ((q >> (v - NV)) & 1u) x = radd<F>(x, elem(q));
+        }
+    }
+    for (uint32_t s = 0; s < tlog; ++s) {
+        uint32_t src = lt;
+        const bool on = planes_partner(lt, tlog, s, v == 1, &src);
+        const BU<F> f = lane_fetch(x, (src & (LPW - 1u)) * T + sub);
+        const BU<F> r = radd<F>(x, f);
+        if (on) x = r;
+    }
+    if (v != 1) {
+        if (lt == 0) x.to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np + (v == 0 ? 0u : (v < NV ? v - 1u : 1u + KLOG + tlog + (v - NV)))) * sizeof(XYZZ<F>)));
+    } else if (lt != 0 && lt < (1u << tlog) && (lt & (lt - 1)) == 0) {
+        x.to_packed(reinterpret_cast<uint32_t*>(partials + ((size_t)w * np + 1 + KLOG + (31 - __clz(lt))) * sizeof(XYZZ<F>)));
+    }
+}
+template <class F>
+void launch_bucket_planes(hipStream_t st, uint32_t windows, uint32_t half, uint32_t L, uint32_t mlog, const uint8_t* buckets, uint8_t* wvout, uint8_t* partials,
+                          const uint32_t* offset, const uint32_t* count, uint32_t gb0, uint32_t NB) {
+    constexpr uint32_t KLOG = UKind<F>::type::LANES == 1 ? 6u : 5u;
+    const uint32_t wpw = 1u << mlog;
+    k_bucket_planes<F><<<windows * wpw, 64, 0, st>>>(buckets, half, L, wpw, wvout, partials, offset, count, gb0, NB);
+    if (wpw > 1) k_planes_combine<F><<<windows * (KLOG + 2u + (mlog > KLOG ? mlog - KLOG : 0u)), 64, 0, st>>>(wvout, half, mlog, partials, offset, count, gb0, NB);
+}
+// logical lanes of a wave in the plane kernels, as a power of two
+template <class F>
+uint32_t planes_lane_bits() {
+    return UKind<F>::type::LANES == 1 ? 6u : 5u;
+}
 
 // The same reduction for G1 with every point split over a lane pair (XYZZH, curve_u.hpp): the dependent chain of a lane is 8 instead
 // of 14 field products per addition and its live state halves (two such waves fit a SIMD beside an accumulation wave).  Logical lane
@@ -783,6 +945,9 @@ uint32_t lanes_per_point() {
 #define MSM_INSTANTIATE_REDUCE(F)                                                                                                            \
     template void launch_bucket_reduce<F>(hipStream_t, uint32_t, uint32_t, const uint8_t*, uint32_t, uint32_t, uint32_t, uint32_t, uint8_t*, const uint32_t*, \
                                           const uint32_t*, uint32_t, uint32_t); \
+    template void launch_bucket_planes<F>(hipStream_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint8_t*, uint8_t*, uint8_t*, const uint32_t*, \
+                                          const uint32_t*, uint32_t, uint32_t); \
+    template uint32_t planes_lane_bits<F>();                                                                                                  \
     template size_t bucket_bytes<F>();                                                                                                        \
     template uint32_t lanes_per_point<F>();
 #define MSM_INSTANTIATE_TAIL_AND_REDUCE(F) MSM_INSTANTIATE_TAIL(F) MSM_INSTANTIATE_REDUCE(F)

@@ -43,6 +43,11 @@ void launch_bucket_reduce(hipStream_t st, uint32_t nparts, uint32_t rblock, cons
                           uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
                           uint32_t gb0, uint32_t NB);
 template <class F>
+void launch_bucket_planes(hipStream_t st, uint32_t windows, uint32_t half, uint32_t L, uint32_t mlog, const uint8_t* buckets, uint8_t* wvout, uint8_t* partials,
+                          const uint32_t* offset, const uint32_t* count, uint32_t gb0, uint32_t NB);   // the reduction as plain sums (bit planes)
+template <class F>
+uint32_t planes_lane_bits();   // log2 of the points one wave holds in the plane kernels
+template <class F>
 void launch_bucket_reduce_pair(hipStream_t st, uint32_t nparts, uint32_t rblock, const uint8_t* buckets, uint32_t half, uint32_t L,
                                uint32_t lanes_per_window, uint32_t wgs_per_window, uint8_t* partials, const uint32_t* offset, const uint32_t* count,
                                uint32_t gb0, uint32_t NB);   // G1 only: every point of the reduction on a lane pair (XYZZH, curve_u.hpp)
@@ -889,13 +894,45 @@ int MsmCall<F>::reduce() {
         p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
         return p;
     };
-    const Plan p0 = plan(split), p1 = plan(NB - split);
+    Plan p0 = plan(split), p1 = plan(NB - split);
+    // Round 4: the reduction as plain sums (k_bucket_planes: no double-and-add on the GPU, the host's Horner pass applies the weights;
+    // one wave is the unit of work).  Buckets per lane: a lone call wants one wave per SIMD and the shortest chain (2L + 7 additions, then
+    // the window's 6); small calls in flight the same, their slots wait for this chain (n = 2^16, three in flight, L = 2 | 4 | 8 | 16:
+    // 0.463 | 0.415 | 0.438 | 0.501 ms per call; k_bucket_reduce 0.484).  The large pipelined calls keep k_bucket_reduce: their reduction waits
+    // for register room beside the next call's accumulation either way, and two launches wait twice (G1, n = 2^20: 2.65 against 2.55 ms for
+    // BLS12-381, 1.42 against 1.35 for BN254; from n = 2^22 on, and for G2, the plane kernels win again: 10.6 against 10.8 ms, 2.56 against 2.68).
+    uint32_t planes_mlog = 0, planes_L = 0;
+    const bool planes_hidden = others_pending && g.c <= 16 && (uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1;
+    bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && w_split == g.Wl && g.half >= 256;
+    if (planes) {
+        const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
+        uint32_t L = std::max(4u, others_pending && g.c <= 16 ? p0.L / 2 : p0.L);
+        if (ctx->force_L) L = std::max(2u, ctx->force_L);
+        while (L > 2 && g.half / L < lpw) L /= 2;
+        // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
+        const uint32_t L_rule = L;
+        while (g.half / (L * lpw) > 4 * lpw) L *= 2;
+        if (L > 2 * L_rule && ctx->reduce_planes != 2) planes = false;   // (one very wide window -- a prepared table's: k_bucket_reduce's chain is the shorter one)
+        if (L > 256) planes = false;
+        planes_L = L;
+        for (planes_mlog = 0; ((uint64_t)L * lpw << planes_mlog) < g.half; ++planes_mlog) {}
+        if (planes) {
+            p0.L = L;
+            p0.wgs = 1 + kl + planes_mlog;   // partials per window
+        }
+    }
     const uint32_t nparts0 = w_split * p0.wgs, nparts1 = (g.Wl - w_split) * p1.wgs, nparts = nparts0 + nparts1;
     sl->part_off.assign(g.Wl, 0);
     sl->part_cnt.assign(g.Wl, 0);
     for (uint32_t wl = 0; wl < g.Wl; ++wl) {
         sl->part_off[wl] = wl < w_split ? wl * p0.wgs : nparts0 + (wl - w_split) * p1.wgs;
         sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
+    }
+    sl->plane_shift = -1;
+    if (planes) {
+        for (sl->plane_shift = 0; (1u << sl->plane_shift) < planes_L; ++sl->plane_shift) {}
+        if (planes_mlog)
+            if (int rc = ensure(ctx, sl->d_planes, ((size_t)g.Wl << planes_mlog) * (planes_lane_bits<FK>() + 2) * BSZ)) return rc;
     }
     if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ + 64)) return rc;   // the partials, then the eight tail words (k_collect_tail)
     if (sl->h_partials_cap < (size_t)nparts * XSZ + 64) {
@@ -919,7 +956,8 @@ int MsmCall<F>::reduce() {
         }
         launch_bucket_reduce<FK>(s_, np, pl.rblock, bk, g.half, pl.L, pl.lanes, pl.wgs, part, offset, count, gb0_, NB);
     };
-    reduce(sb, nparts0, p0, buckets, partials, 0);
+    if (planes) launch_bucket_planes<FK>(sb, g.Wl, g.half, planes_L, planes_mlog, buckets, (uint8_t*)sl->d_planes.p, partials, offset, count, 0, NB);
+    else reduce(sb, nparts0, p0, buckets, partials, 0);
     if (nparts1) {
         hipStream_t sc = sl->stream_c;
         HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
@@ -1017,6 +1055,22 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
     const HX* parts = reinterpret_cast<const HX*>(sl->h_partials);
     HX total = HX::inf();
     int prev_w = -1;   // global index of the window most recently folded in
+    if (sl->plane_shift >= 0) {
+        // bit planes (k_bucket_planes): partial 0 of a window weighs 1, partial 1+b weighs 2^(b + plane_shift) -- all below the window's
+        // width, so one pass from the top bit down meets them in order: as many doublings as before, one addition per partial
+        int pos = -1;   // bit position `total` currently stands at
+        for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
+            const int wglob = g.merged ? 0 : wl * (int)g.nshards + (int)g.shard;
+            const int start = (int)window_start_bit(g, (uint32_t)wglob);
+            for (int k = (int)sl->part_cnt[wl] - 1; k >= 0; --k) {
+                const int at = start + (k == 0 ? 0 : k - 1 + sl->plane_shift);
+                for (; pos > at; --pos) total = HX::dbl(total);
+                pos = at;
+                total = HX::add(total, parts[(size_t)sl->part_off[wl] + k]);
+            }
+        }
+        for (; pos > 0; --pos) total = HX::dbl(total);
+    } else {
     for (int wl = (int)g.Wl - 1; wl >= 0; --wl) {
         int wglob = g.merged ? 0 : wl * (int)g.nshards + (int)g.shard;   // (prepared table: the window weights are in the table)
         if (prev_w >= 0)
@@ -1027,6 +1081,7 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         prev_w = wglob;
     }
     for (int k = 0; prev_w > 0 && k < (int)window_start_bit(g, (uint32_t)prev_w); ++k) total = HX::dbl(total);
+    }
     if (sl->raw_out) host_store_jacobian_raw(total, out);
     else host_store_jacobian_normalised(total, out);
     auto t1 = std::chrono::steady_clock::now();

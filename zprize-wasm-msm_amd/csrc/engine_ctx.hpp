@@ -70,6 +70,8 @@ struct RunArgs {
 // the sort + accumulation of the next call (throughput-bound, stream A).
 struct Slot {
     DevBuf d_itab;    // the work list's two class prefix tables (k_items_plan)
+    DevBuf d_planes;  // bit-plane reduction: what the workgroups of a window leave for k_planes_combine
+    int plane_shift = -1;   // >= 0: the partials of a window are bit planes (finish_msm: partial 1+b weighs 2^(b + plane_shift)); -1: equal weights
     DevBuf d_halves, d_tmp, d_binhist, d_binstart, d_bincur, d_cpre, d_desc, d_bcursor, d_tailctl, d_work, d_biglist, d_segout, d_slices;
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
@@ -96,7 +98,7 @@ struct Slot {
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
     RunArgs retry_args{};            // what was submitted, kept so that the collector can run the call again (narrow layout met a wide scalar)
     int retry_curve = 0, retry_group = 0;
-    DevBuf* bufs[26] = {&d_itab, &d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
+    DevBuf* bufs[27] = {&d_planes, &d_itab, &d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
                         &d_affine, &d_count, &d_offset, &d_order, &d_bins, &d_sorted, &d_buckets, &d_partials};
 };
 
@@ -189,6 +191,7 @@ struct msm_amd_ctx {
     std::string err;
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
+    int reduce_planes = 1;   // option "reduce_planes": the bucket reduction as plain sums (k_bucket_planes): 1 = where it pays (reduce()), 2 = wherever it can, 0 = k_bucket_reduce always
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int no_hot = 0;         // option "hot" = 0: no short segments / grouped fold for hot buckets
     int zero_copy = 1;      // option "zero_copy" (default 1): the reduction writes its partials and the tail words straight into the pinned host buffer -- no copy back (15 us of every call); 0 = device buffer + one copy
