@@ -114,6 +114,8 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  *   sort_geom        partition geometry: 0 round 4's by size, 1 round 3's (256 coarse bins, 9216-entry spans), 2 = 512 bins wherever the
  *                    window allows, 3 = 2 + the 1024-lane fine sort
  *   reduce_l         buckets per lane of the bucket reduction (a power of two)
+ *   reduce_planes    the bucket reduction as plain sums whose weights the host's Horner pass applies (k_bucket_planes): 1 (default) where it
+ *                    pays, 2 wherever it can, 0 never (k_bucket_reduce: running sums + a double-and-add per lane)
  *
  *   -- experiments that were measured and left off, kept for re-measurement ---------------------------------------------------------
  *   split (1 = reduce a lone call's windows in two overlapping groups: slower), reduce_pair (1 = the G1 reduction on lane pairs: no gain),
