@@ -902,11 +902,14 @@ int MsmCall<F>::reduce() {
     // for register room beside the next call's accumulation either way, and two launches wait twice (G1, n = 2^20: 2.65 against 2.55 ms for
     // BLS12-381, 1.42 against 1.35 for BN254; from n = 2^22 on, and for G2, the plane kernels win again: 10.6 against 10.8 ms, 2.56 against 2.68).
     uint32_t planes_mlog = 0, planes_L = 0;
-    const bool planes_hidden = others_pending && g.c <= 16 && (uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1;
+    // (... as long as that accumulation is the long one: with fewer than 24 entries per bucket on average -- the last call of the same shape
+    // says -- it is not, and the reduction's chain is what a slot waits for: witness-like scalars at n = 2^20, profiles/r04_witness_like_sparse.txt)
+    const bool sparse = ctx->fill_nb.load() == NB && ctx->fill_mean16.load() < 24u * 16u;
+    const bool planes_hidden = others_pending && !sparse && g.c <= 16 && (uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1;
     bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && w_split == g.Wl && g.half >= 256;
     if (planes) {
         const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
-        uint32_t L = std::max(4u, others_pending && g.c <= 16 ? p0.L / 2 : p0.L);
+        uint32_t L = std::max(4u, others_pending && g.c <= 16 ? (sparse ? std::min(8u, p0.L / 2) : p0.L / 2) : p0.L);
         if (ctx->force_L) L = std::max(2u, ctx->force_L);
         while (L > 2 && g.half / L < lpw) L /= 2;
         // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
@@ -1013,6 +1016,10 @@ static int finish_msm(msm_amd_ctx* ctx, Slot* sl, uint8_t* out) {
         // means long spans in the fine sort as well, which the sort only cuts into parallel chunks when it expects them: the next
         // calls of this context do (n = 2^20, 256-bit scalars: scatter stage 1.7 -> 0.3 ms from the second call on).
         if (getenv("MSM_AMD_DEBUG_TAIL")) fprintf(stderr, "msm_amd tail: %u segments, %u big buckets, %u hot\n", h_tail[2], h_tail[3], h_tail[4]);
+        if (g.nshards == 1 && sl->NB) {
+            ctx->fill_nb.store(sl->NB);
+            ctx->fill_mean16.store((uint32_t)std::min<uint64_t>(entries * 16u / sl->NB, 0xffffffffu));
+        }
         if (h_tail[3] /* TailCtl::nbig */ > 0) ctx->skew_hint.store(16);
         else if (ctx->skew_hint.load() > 0) ctx->skew_hint.fetch_sub(1);
         // entries in the overflow window (plan()): the scalars are wider than the group order -- the next calls tile the declared width

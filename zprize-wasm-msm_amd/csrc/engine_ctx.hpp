@@ -191,6 +191,10 @@ struct msm_amd_ctx {
     std::string err;
     uint32_t force_c = 0;
     uint32_t force_seg = 0; // MSM_AMD_SEG: bucket segment length (tests force splitting with a small value)
+    // what the last finished call put into its buckets: its bucket count and 16 x the mean entries per bucket.  A call with the same bucket
+    // count takes it as the expected density of its own input (reduce(): sparse inputs -- a witness full of zeros, ones and small values --
+    // have a short accumulation that cannot hide a long reduction)
+    std::atomic<uint32_t> fill_nb{0}, fill_mean16{0};
     int reduce_planes = 1;   // option "reduce_planes": the bucket reduction as plain sums (k_bucket_planes): 1 = where it pays (reduce()), 2 = wherever it can, 0 = k_bucket_reduce always
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int no_hot = 0;         // option "hot" = 0: no short segments / grouped fold for hot buckets
