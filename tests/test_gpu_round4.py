@@ -444,3 +444,28 @@ def test_reduction_as_plain_sums(orc, curve, group, n, c, rl):
         assert _f(C, group)(bases, scalars, 32, n) == exp
     finally:
         eng.close()
+
+
+def test_reduction_follows_the_reported_density(orc):
+    """reduce(): a pipelined call of the headline's shape (16-bit windows, >= 2^19 buckets) keeps k_bucket_reduce only while its buckets are
+    expected to be full; once a call of the same shape has reported fewer than 24 entries per bucket, the next ones in flight take the plane
+    kernels.  Both give the oracle's bytes, in either order, with one or two calls in flight."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_window_bits(16)
+        C = eng.curve("bls12381")
+        O = orc.Oracle("bls12381", 1)
+        n = 6000
+        bases, scalars = gu.random_case("bls12381", 1, "gpu:density", n)
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        ts = [C.multiexp_async(1, bases, scalars, 32, n) for _ in range(2)]     # nothing reported yet: the second one is "hidden" -> k_bucket_reduce
+        assert [t.wait() for t in ts] == [exp, exp]
+        for _ in range(3):                                                       # 0.2 entries per bucket reported: plane kernels for calls in flight
+            ts = [C.multiexp_async(1, bases, scalars, 32, n) for _ in range(2)]
+            assert [t.wait() for t in ts] == [exp, exp]
+        eng.set_option("reduce_planes", 0)
+        ts = [C.multiexp_async(1, bases, scalars, 32, n) for _ in range(2)]
+        assert [t.wait() for t in ts] == [exp, exp]
+    finally:
+        eng.close()
