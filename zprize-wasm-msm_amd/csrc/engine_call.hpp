@@ -905,7 +905,9 @@ int MsmCall<F>::reduce() {
     // (... as long as that accumulation is the long one: with fewer than 24 entries per bucket on average -- the last call of the same shape
     // says -- it is not, and the reduction's chain is what a slot waits for: witness-like scalars at n = 2^20, profiles/r04_witness_like_sparse.txt)
     const bool sparse = ctx->fill_nb.load() == NB && ctx->fill_mean16.load() < 24u * 16u;
-    const bool planes_hidden = others_pending && !sparse && g.c <= 16 && (uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1;
+    // (windows above 16 bits, other calls in flight: k_bucket_reduce as well -- n = 2^23, c = 19: 19.3 against 21.5 ms per call; c = 20 even)
+    const bool planes_hidden = others_pending && !sparse &&
+                               (g.c > 16 || ((uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1));
     bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && w_split == g.Wl && g.half >= 256;
     if (planes) {
         const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
@@ -915,7 +917,9 @@ int MsmCall<F>::reduce() {
         // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
         const uint32_t L_rule = L;
         while (g.half / (L * lpw) > 4 * lpw) L *= 2;
-        if (L > 2 * L_rule && ctx->reduce_planes != 2) planes = false;   // (one very wide window -- a prepared table's: k_bucket_reduce's chain is the shorter one)
+        // (a single very wide window -- a prepared table's merged windows -- would need longer running sums than k_bucket_reduce's rule gives
+        // it: that kernel's chain is the shorter one there, 2.46 against 2.88 ms per call at n = 2^20 prepared)
+        if ((L != L_rule || g.merged) && ctx->reduce_planes != 2) planes = false;
         if (L > 256) planes = false;
         planes_L = L;
         for (planes_mlog = 0; ((uint64_t)L * lpw << planes_mlog) < g.half; ++planes_mlog) {}
