@@ -226,6 +226,10 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
     uint32_t* h = smem_u32;
     const uint32_t tile = blockIdx.x;
     const uint32_t rows = g.merged ? g.W : g.Wl, nh = rows * sg.cb;
+    __shared__ uint32_t widest;   // of this workgroup's scalars
+    // (read at the top, used after the last barrier: the round trip is hidden behind the pass)
+    const uint32_t widest_so_far = NW == 8 && threadIdx.x == 0 ? *reinterpret_cast<const volatile uint32_t*>(too_wide + 1) : 0u;
+    if (threadIdx.x == 0) widest = 0;
     for (uint32_t s = threadIdx.x; s < nh; s += BLOCK) h[s] = 0;
     __syncthreads();
     DigitSource<NW, ITEMS, BLOCK> ds;
@@ -244,9 +248,9 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
         }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, d, 64));
-        // (one atomic per wave on ONE address serialises: 4096 of them took 30 us of this kernel's 55 at n = 2^20.  Only a wave that would
-        // raise the maximum sends one -- uniform scalars settle it within the first few waves; a stale read merely costs an atomic)
-        if ((threadIdx.x & 63u) == 0 && mb > *reinterpret_cast<const volatile uint32_t*>(too_wide + 1)) atomicMax(too_wide + 1, mb);
+        // (one global atomic per wave on ONE address serialises -- 4096 of them took 30 us of this kernel's 55 at n = 2^20: the waves meet
+        // in LDS, and only a workgroup that would raise the maximum sends one, at its end; uniform scalars settle it within the first few)
+        if ((threadIdx.x & 63u) == 0 && mb) atomicMax(&widest, mb);
     }
     for (uint32_t w = 0; w < g.W; ++w) {
         const bool owned = g.merged || (w % g.nshards) == g.shard;
@@ -266,6 +270,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_hist(const uint8_t* __restrict__
         if (wide) atomicOr(too_wide, 1u);
     }
     __syncthreads();
+    if (NW == 8 && threadIdx.x == 0 && widest > widest_so_far) atomicMax(too_wide + 1, widest);
     for (uint32_t s = threadIdx.x; s < nh; s += BLOCK) {
         const uint32_t v = h[s];
         if (v) {
