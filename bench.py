@@ -329,8 +329,8 @@ def main():
     # How many: one probe call tells what a call (of this rank) consists of -- profiles/r03_shard_per_rank_table.txt measured every
     # share with two, three and four in flight.  A call whose accumulation is small -- fewer than 327 680 buckets, so that it runs on
     # its slot's own stream beside the others', and not in the 8-bit-window regime, whose 64-lane slices fill the chip already --
-    # is best served by four in flight below ~1 M (pair, window) entries and by three up to ~10 M: n = 2^15 ... 2^18 on one GPU (2^18 at
-    # 14-bit windows: 1.22 | 1.02 | 1.15 ms with 2 | 3 | 4 in flight), the window groups of a sharded n <= 2^20.  Everything else: two.
+    # is best served by three in flight up to ~10 M (pair, window) entries: n = 2^15 ... 2^18 on one GPU (2^18 at
+    # 14-bit windows: 1.06 | 0.92 | 1.01 ms with 2 | 3 | 4 in flight), the window groups of a sharded n <= 2^20.  Everything else: two.
     depth = 1
     if pipelined:
         depth = args.depth or 2
@@ -346,7 +346,9 @@ def main():
             if prep is not None:
                 want = 4 if (small_acc and gm["entries"] < 3500000) else 2
             else:
-                want = (4 if gm["entries"] < 1000000 else (3 if gm["entries"] < 10000000 else 2)) if small_acc else 2
+                # (round 4, with the cheaper reduction: three beat four at every small size -- n = 2^15: 0.427 | 0.323 | 0.386 | 0.375 ms with
+                # 2 | 3 | 4 | 5 in flight, n = 2^16: 0.527 | 0.418 | 0.483 | 0.459; profiles/r04_depth_small_n_planes.txt)
+                want = (3 if gm["entries"] < 10000000 else 2) if small_acc else 2
             if sharded:
                 flag = torch.tensor([want], dtype=torch.int32, device=xdev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank keeps the same number of calls in flight
