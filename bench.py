@@ -344,7 +344,8 @@ def main():
             gm = eng.geometry()
             small_acc = gm["windows_owned"] * gm["buckets_per_window"] < 327680 and gm["buckets_per_window"] >= 4096
             if prep is not None:
-                want = 4 if (small_acc and gm["entries"] < 3500000) else 2
+                # (round 4: n = 2^18 prepared, 3.9 M entries: 1.02 | 0.91 | 1.07 ms with 2 | 3 | 4 in flight; profiles/r04_prepared_small_n.txt)
+                want = (4 if gm["entries"] < 3500000 else (3 if gm["entries"] < 10000000 else 2)) if small_acc else 2
             else:
                 # (round 4, with the cheaper reduction: three beat four at every small size -- n = 2^15: 0.427 | 0.323 | 0.386 | 0.375 ms with
                 # 2 | 3 | 4 | 5 in flight, n = 2^16: 0.527 | 0.418 | 0.483 | 0.459; profiles/r04_depth_small_n_planes.txt)

@@ -917,9 +917,9 @@ int MsmCall<F>::reduce() {
         // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
         const uint32_t L_rule = L;
         while (g.half / (L * lpw) > 4 * lpw) L *= 2;
-        // (a single very wide window -- a prepared table's merged windows -- would need longer running sums than k_bucket_reduce's rule gives
-        // it: that kernel's chain is the shorter one there, 2.46 against 2.88 ms per call at n = 2^20 prepared)
-        if ((L != L_rule || g.merged) && ctx->reduce_planes != 2) planes = false;
+        // (a single very wide window -- the merged windows of a prepared table at n = 2^20 -- would need running sums four times as long as
+        // k_bucket_reduce's rule gives it: that kernel's chain is the shorter one there, latency 3.08 against 3.68 ms)
+        if (L > 2 * L_rule && ctx->reduce_planes != 2) planes = false;
         if (L > 256) planes = false;
         planes_L = L;
         for (planes_mlog = 0; ((uint64_t)L * lpw << planes_mlog) < g.half; ++planes_mlog) {}
