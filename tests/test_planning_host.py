@@ -111,10 +111,10 @@ def test_split_is_a_factorisation_and_the_slices_tile_the_points(world):
 
 
 def test_planned_splits_of_the_measured_table():
-    """the plan follows profiles/r03_shard_per_rank_table.txt (busiest rank's share, measured on one MI355X)"""
+    """the plan follows profiles/r04_shard_per_rank_table.txt (busiest rank's share, measured on one MI355X with round 4's kernels)"""
     split = lambda logn, world: (lambda p: (p["gp"], p["gw"]))(msm_amd.plan_split("bls12381", 1, 32, 1 << logn, world, 0))
     assert split(26, 8) == (8, 1) and split(26, 2) == (2, 1)       # large n: along the points, every rank holds 1/8 of the bases
-    assert split(20, 2) == (1, 2) and split(20, 8) == (2, 4)       # the headline size: mostly along the windows
+    assert split(20, 2) == (2, 1) and split(20, 4) == (1, 4) and split(20, 8) == (4, 2)   # the headline size: both seams, by the measured shares
     assert split(16, 8)[0] * split(16, 8)[1] == 8
 
 

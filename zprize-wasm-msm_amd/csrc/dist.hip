@@ -97,24 +97,24 @@ int nccl_fail(msm_amd_ctx* ctx, const char* what, int rc) {
 // alone on one MI355X, profiles/r03_shard_per_rank_table.txt): for every divisor gw of the world size, the time of the busiest rank.
 // kShareMs[log2(points per rank) - 13][log2(window groups)]: ms per call of one rank's share -- window group 0 of gw on a slice of that
 // many points, run alone on one MI355X with two, three or four calls in flight, whichever is fastest (BLS12-381 G1, 255-bit scalars;
-// tools/shard_table.py, profiles/r04_shard_per_rank_table.txt -- re-measured in round 4 with the work list on; tools/fit_share_tables.py: cells the
+// tools/shard_table.py, profiles/r04_shard_per_rank_table.txt -- re-measured in round 4 with the work list and the plane kernels; tools/fit_share_tables.py: cells the
 // sweep does not visit keep the round-3 value scaled by the nearest re-measured cell).
 // Other curves and groups scale the table; the choice of a split only needs its shape.
 static const float kShareMsG1[14][4] = {
-    {0.399f, 0.410f, 0.351f, 0.390f},   // 2^13  (partly scaled from the G1 table)
-    {0.443f, 0.432f, 0.367f, 0.410f},   // 2^14  (partly scaled from the G1 table)
-    {0.405f, 0.445f, 0.367f, 0.410f},   // 2^15  (partly scaled from the G1 table)
-    {0.478f, 0.480f, 0.388f, 0.426f},   // 2^16
-    {0.646f, 0.521f, 0.411f, 0.429f},   // 2^17  (partly scaled from the G1 table)
-    {0.941f, 0.654f, 0.455f, 0.474f},   // 2^18
-    {1.612f, 0.897f, 0.581f, 0.564f},   // 2^19  (partly scaled from the G1 table)
-    {2.621f, 1.477f, 0.870f, 0.750f},   // 2^20
-    {5.182f, 2.919f, 1.528f, 1.098f},   // 2^21  (partly scaled from the G1 table)
-    {10.783f, 6.210f, 3.081f, 1.884f},   // 2^22
-    {19.352f, 10.017f, 6.281f, 3.335f},   // 2^23  (partly scaled from the G1 table)
-    {36.313f, 19.102f, 12.057f, 6.434f},   // 2^24
-    {69.476f, 37.931f, 23.844f, 12.635f},   // 2^25  (partly scaled from the G1 table)
-    {134.995f, 74.916f, 45.646f, 24.207f},   // 2^26
+    {0.391f, 0.401f, 0.344f, 0.382f},   // 2^13  (partly scaled from the G1 table)
+    {0.444f, 0.401f, 0.340f, 0.380f},   // 2^14  (partly scaled from the G1 table)
+    {0.319f, 0.384f, 0.284f, 0.317f},   // 2^15  (partly scaled from the G1 table)
+    {0.414f, 0.384f, 0.297f, 0.357f},   // 2^16
+    {0.589f, 0.406f, 0.314f, 0.328f},   // 2^17  (partly scaled from the G1 table)
+    {0.906f, 0.550f, 0.384f, 0.393f},   // 2^18
+    {1.464f, 0.907f, 0.552f, 0.536f},   // 2^19  (partly scaled from the G1 table)
+    {2.561f, 1.477f, 0.861f, 0.699f},   // 2^20
+    {5.070f, 3.053f, 1.587f, 1.140f},   // 2^21  (partly scaled from the G1 table)
+    {10.208f, 6.297f, 3.032f, 1.784f},   // 2^22
+    {18.744f, 9.651f, 5.920f, 3.143f},   // 2^23  (partly scaled from the G1 table)
+    {35.458f, 18.595f, 11.973f, 6.127f},   // 2^24
+    {67.586f, 37.081f, 23.423f, 12.412f},   // 2^25  (partly scaled from the G1 table)
+    {130.893f, 73.006f, 44.413f, 23.578f},   // 2^26
 };
 // The same for BN254 G1 and for G2 (round 4; tools/shard_table.py --curve bn128 / --group 2, profiles/r04_shard_table_*.txt, built with
 // tools/fit_share_tables.py: a cell is the best of two, three and four calls in flight; cells the sweeps did not visit are the G1 table's
