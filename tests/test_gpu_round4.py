@@ -334,8 +334,8 @@ def _seeds(default):
 def test_randomised_round4_configurations(orc, seed):
     """50 seeded random combinations of what round 4 added or touched: the work list on / off / forced with random lane lengths, every
     partition geometry with either tile size, wide and narrow windows, scalar sizes the window does or does not divide, uniform / full-width /
-    short / heavily repeated scalars (long and hot buckets: the inlined tail kernels), synchronous, two in flight, prepared tables and
-    hybrid shards summed on this GPU -- each against the oracle."""
+    short / heavily repeated scalars (long and hot buckets: the inlined tail kernels), both forms of the bucket reduction with random
+    running-sum lengths, synchronous, two in flight, prepared tables and hybrid shards summed on this GPU -- each against the oracle."""
     import msm_amd
     from msm_amd import dist as mdist
     rnd = random.Random(seed)
@@ -367,7 +367,8 @@ def test_randomised_round4_configurations(orc, seed):
                         sc[i * ss:(i + 1) * ss] = raw[j * ss:(j + 1) * ss] if j < n else raw[:ss]
             scalars = bytes(sc)
             opts = {"items": rnd.choice([0, 1, 1, 2]), "items_t": rnd.choice([0, 0, 8, 9, 16, 40, 300]), "sort_geom": rnd.choice([0, 0, 1, 2, 3]),
-                    "tile_mode": rnd.choice([0, 1, 2, 2]), "sort_big": rnd.choice([0, 0, 1, 2]), "hot": rnd.choice([1, 1, 0])}
+                    "tile_mode": rnd.choice([0, 1, 2, 2]), "sort_big": rnd.choice([0, 0, 1, 2]), "hot": rnd.choice([1, 1, 0]),
+                    "reduce_planes": rnd.choice([1, 1, 2, 2, 0]), "reduce_l": rnd.choice([0, 0, 0, 2, 4, 8, 32])}
             for k, v in opts.items():
                 eng.set_option(k, v)
             c = rnd.choice([0, 0, 4, 9, 11, 13, 14, 16, 18, 19, 20, 21])
