@@ -390,7 +390,9 @@ int msm_amd_get_timings(const msm_amd_ctx *ctx, float *ms, int capacity);
  * [4],[5] low/high word of the number of (pair, window) entries scattered into buckets */
 int msm_amd_get_geometry(const msm_amd_ctx *ctx, uint32_t *out6);
 /* The call-to-call state that shapes a context's next calls: [0] calls left in the wide layout (recent scalars used
- * bits beyond the group order's width), [1] calls left expecting skew (recent calls queued over-long buckets), [2] slots, [3] entries per
+ * bits beyond the group order's width), [1] calls left expecting skew (recent calls queued over-long buckets), [2] slots in the low 16 bits,
+ * the mean number of entries per bucket the last call reported (what the next call of the same shape expects: sparse inputs take the
+ * reduction with the short chain) in the high 16, [3] entries per
  * lane of the accumulation's work list in the call planned last (0: one lane per bucket, or slices) in the low 16 bits, the observed
  * scalar width the next calls' windows tile (0: none -- the group order's) in the high 16.  A measurement reports them. */
 int msm_amd_get_hints(const msm_amd_ctx *ctx, uint32_t *out4);

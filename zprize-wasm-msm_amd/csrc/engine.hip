@@ -739,7 +739,7 @@ int msm_amd_get_hints(const msm_amd_ctx* ctx, uint32_t* out4) {
     if (!ctx || !out4) return MSM_AMD_EINVAL;
     out4[0] = (uint32_t)std::max(0, ctx->wide_hint.load());
     out4[1] = (uint32_t)std::max(0, ctx->skew_hint.load());
-    out4[2] = ctx->nslots;
+    out4[2] = ctx->nslots | (std::min<uint32_t>(ctx->fill_mean16.load() / 16u, 0xffffu) << 16);
     out4[3] = ctx->last_items_T | ((uint32_t)std::max(0, ctx->narrow_bits.load()) << 16);
     return 0;
 }

@@ -269,11 +269,11 @@ class Engine:
         return {names[i]: float(arr[i]) for i in range(k)}
 
     def hints(self):
-        """msm_amd_get_hints: the call-to-call state of the context -- {wide, skew: calls left in that layout, slots, work_list_T, narrow_bits: the observed scalar width the next calls tile}"""
+        """msm_amd_get_hints: the call-to-call state of the context -- {wide, skew: calls left in that layout, slots, entries_per_bucket: what the last call reported (the density the next one expects), work_list_T, narrow_bits: the observed scalar width the next calls tile}"""
         arr = (ctypes.c_uint32 * 4)()
         self.L.msm_amd_get_hints.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.L.msm_amd_get_hints(self.ctx, arr)
-        return {"wide": arr[0], "skew": arr[1], "slots": arr[2], "work_list_T": arr[3] & 0xffff, "narrow_bits": arr[3] >> 16}
+        return {"wide": arr[0], "skew": arr[1], "slots": arr[2] & 0xffff, "entries_per_bucket": arr[2] >> 16, "work_list_T": arr[3] & 0xffff, "narrow_bits": arr[3] >> 16}
 
     def geometry(self):
         arr = (ctypes.c_uint32 * 6)()
