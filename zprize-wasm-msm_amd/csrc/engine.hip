@@ -127,6 +127,8 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
     }
     if (rc) {
         sl->binhist_zero.clear();   // whatever the sort had counted so far is not to be trusted
+        sl->ctl_zero.clear();
+        sl->flags_zero.clear();
         // leave the streams clean so the context stays usable
         (void)hipStreamSynchronize(ctx->stream_s);
         if (ctx->stream_s2) (void)hipStreamSynchronize(ctx->stream_s2);

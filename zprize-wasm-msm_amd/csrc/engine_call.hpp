@@ -595,7 +595,8 @@ int MsmCall<F>::sort() {
     // binhist is all zero between calls: zeroed when (re)allocated, dirtied by k_tile_hist in [0, nbins), zeroed again by k_bin_scan
     if (!sl->binhist_zero.holds(sl->d_binhist)) HIPCHK(ctx, hipMemsetAsync(binhist, 0, sl->d_binhist.cap, st));
     sl->binhist_zero.clear();   // until this submission has got as far as k_bin_scan
-    HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
+    if (!sl->flags_zero.holds(sl->d_flags)) HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
+    sl->flags_zero.clear();   // until this submission has got as far as k_collect_tail
 #define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist, (uint32_t*)sl->d_flags.p)
     if (wide) {
         if (nw == 8) MSM_TILE_HIST(8, 1024);
@@ -812,7 +813,8 @@ int MsmCall<F>::accumulate() {
     // G1 has two builds of the accumulation kernels (bucket_kernels.hpp): the chained one when the launch puts at least two waves
     // on every SIMD, the two-chain one otherwise
     auto accumulate = [&](const uint32_t* ord, uint32_t nbk, uint32_t k) -> int {
-        HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+        if (!sl->ctl_zero.holds(sl->d_tailctl)) HIPCHK(ctx, hipMemsetAsync(sl->d_tailctl.p, 0, 16, st));
+        sl->ctl_zero.clear();   // (a second group of a split call zeroes them itself; k_collect_tail sets the mark again)
         if (items_T) {   // (one group only: plan() keeps the work list off when the call is split)
             const uint32_t* itab = (const uint32_t*)sl->d_itab.p;
             uint8_t* items_out = (uint8_t*)sl->d_slices.p;
@@ -976,8 +978,10 @@ int MsmCall<F>::reduce() {
     // one copy: the partials and, behind them, the tail words -- total number of scattered (pair, window) entries = last offset + last
     // count (roofline accounting); the tail counters of the (last) accumulation: buckets that overflowed their segment tell the next
     // calls that the input is skewed; scalars wider than a prepared table's windows; where the top owned window's entries start
-    k_collect_tail<<<1, 64, 0, sb>>>(offset, count, NB, (g.Wl - 1) * g.half, (const uint32_t*)sl->d_tailctl.p, (const uint32_t*)sl->d_flags.p,
+    k_collect_tail<<<1, 64, 0, sb>>>(offset, count, NB, (g.Wl - 1) * g.half, (uint32_t*)sl->d_tailctl.p, (uint32_t*)sl->d_flags.p,
                                      reinterpret_cast<uint32_t*>(partials + (size_t)nparts * XSZ));
+    sl->ctl_zero.set(sl->d_tailctl);
+    sl->flags_zero.set(sl->d_flags);
     if (!ctx->zero_copy) HIPCHK(ctx, hipMemcpyAsync(sl->h_partials, sl->d_partials.p, (size_t)nparts * XSZ + 48, hipMemcpyDeviceToHost, sb));
     HIPCHK(ctx, hipEventRecord(sl->ev[7], sb));
     const uint32_t wgs_per_window = p0.wgs;

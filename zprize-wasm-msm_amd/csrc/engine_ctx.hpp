@@ -76,6 +76,7 @@ struct Slot {
     DevBuf d_xbeta;   // GLV path: beta * x of every base
     DevBuf d_bases, d_scalars, d_affine, d_count, d_offset, d_order, d_bins, d_sorted, d_buckets, d_partials;
     ZeroMark binhist_zero;        // holds(d_binhist) while that buffer is known to be all zero (sort: k_bin_scan leaves it so)
+    ZeroMark ctl_zero, flags_zero;   // the same for the first 16 bytes of d_tailctl and d_flags (k_collect_tail leaves them so)
     void* h_partials = nullptr;   // pinned
     size_t h_partials_cap = 0;
     hipEvent_t ev[10] = {};       // stage boundaries; ev[8] = accumulation done (stream A -> stream B dependency); ev[9] = accumulation starts

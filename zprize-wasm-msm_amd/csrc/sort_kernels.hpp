@@ -135,8 +135,10 @@ struct DigitSource {
 // The few words the host wants beside the window partials -- where the last bucket's entries end (= the number of entries), the tail
 // counters, the too-wide flag of a prepared table, where the top owned window's entries start -- gathered behind the partials so that
 // ONE copy brings everything back (six separate 4- to 16-byte copies cost ~40 us at the end of every call).
+// Having read them it zeroes the four tail counters and the two flag words: they are all zero between the calls of a slot (round 4 -- the
+// two 16-byte memsets at the head of every call's sort and accumulation are gone; Slot::ctl_zero / flags_zero say when that holds).
 __global__ void k_collect_tail(const uint32_t* __restrict__ offset, const uint32_t* __restrict__ count, uint32_t NB, uint32_t top_first,
-                               const uint32_t* __restrict__ tailctl, const uint32_t* __restrict__ flags, uint32_t* __restrict__ out) {
+                               uint32_t* __restrict__ tailctl, uint32_t* __restrict__ flags, uint32_t* __restrict__ out) {
     if (threadIdx.x == 0) {
         out[0] = offset[NB - 1];
         out[1] = count[NB - 1];
@@ -147,6 +149,8 @@ __global__ void k_collect_tail(const uint32_t* __restrict__ offset, const uint32
         out[6] = flags[0];
         out[7] = offset[top_first];
         out[8] = flags[1];   // significant bits of the widest scalar (k_tile_hist; 0 = not measured)
+        tailctl[0] = tailctl[1] = tailctl[2] = tailctl[3] = 0;
+        flags[0] = flags[1] = flags[2] = flags[3] = 0;
     }
 }
 
