@@ -455,7 +455,8 @@ int MsmCall<F>::plan() {
     // on one wave per SIMD.  Optionally (option "split") its windows are handled as two groups, the reduction of the first
     // group running under the accumulation of the second.  Measured at n = 2^20 this LOSES (6.3 vs 4.8 ms): the 256-VGPR
     // reduction waves leave room for only one accumulation wave per SIMD, and two launches have two tails.  Kept for
-    // experiments, off by default; overlapping across calls (slots) is what pays.
+    // experiments, off by default; overlapping across calls (slots) is what pays.  (Round 4, with the plane kernels reducing both
+    // groups: still 3.74 against 3.14 ms at n = 2^20, 11.98 against 11.25 at 2^22 -- tools/runs/r04_split_planes.sh.)
     split_mode = !others_pending && !ctx->no_split && g.Wl >= 6 && NB >= 8u * 65536u;
     w_split = split_mode ? g.Wl - std::max(2u, (g.Wl * 3u) / 10u) : g.Wl;   // windows in the first group
     split = w_split * g.half;                                               // first bucket of the second group
@@ -910,7 +911,7 @@ int MsmCall<F>::reduce() {
     // (windows above 16 bits, other calls in flight: k_bucket_reduce as well -- n = 2^23, c = 19: 19.3 against 21.5 ms per call; c = 20 even)
     const bool planes_hidden = others_pending && !sparse &&
                                (g.c > 16 || ((uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1));
-    bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && w_split == g.Wl && g.half >= 256;
+    bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && g.half >= 256;
     if (planes) {
         const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
         uint32_t L = std::max(4u, others_pending && g.c <= 16 ? (sparse ? std::min(8u, p0.L / 2) : p0.L / 2) : p0.L);
@@ -928,6 +929,7 @@ int MsmCall<F>::reduce() {
         if (planes) {
             p0.L = L;
             p0.wgs = 1 + kl + planes_mlog;   // partials per window
+            p1 = p0;                         // (a split call: both window groups the same way)
         }
     }
     const uint32_t nparts0 = w_split * p0.wgs, nparts1 = (g.Wl - w_split) * p1.wgs, nparts = nparts0 + nparts1;
@@ -965,12 +967,16 @@ int MsmCall<F>::reduce() {
         }
         launch_bucket_reduce<FK>(s_, np, pl.rblock, bk, g.half, pl.L, pl.lanes, pl.wgs, part, offset, count, gb0_, NB);
     };
-    if (planes) launch_bucket_planes<FK>(sb, g.Wl, g.half, planes_L, planes_mlog, buckets, (uint8_t*)sl->d_planes.p, partials, offset, count, 0, NB);
+    if (planes) launch_bucket_planes<FK>(sb, w_split, g.half, planes_L, planes_mlog, buckets, (uint8_t*)sl->d_planes.p, partials, offset, count, 0, NB);
     else reduce(sb, nparts0, p0, buckets, partials, 0);
     if (nparts1) {
         hipStream_t sc = sl->stream_c;
         HIPCHK(ctx, hipStreamWaitEvent(sc, sl->ev[5], 0));
-        reduce(sc, nparts1, p1, buckets + (size_t)split * BSZ, partials + (size_t)nparts0 * XSZ, split);
+        if (planes)
+            launch_bucket_planes<FK>(sc, g.Wl - w_split, g.half, planes_L, planes_mlog, buckets + (size_t)split * BSZ,
+                                     (uint8_t*)sl->d_planes.p + ((size_t)w_split << planes_mlog) * (planes_lane_bits<FK>() + 2) * BSZ, partials + (size_t)nparts0 * XSZ,
+                                     offset, count, split, NB);
+        else reduce(sc, nparts1, p1, buckets + (size_t)split * BSZ, partials + (size_t)nparts0 * XSZ, split);
         HIPCHK(ctx, hipEventRecord(sl->ev_c, sc));
         HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev_c, 0));
     }
