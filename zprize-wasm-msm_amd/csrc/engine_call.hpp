@@ -875,63 +875,76 @@ int MsmCall<F>::reduce() {
     struct Plan {
         uint32_t L, lanes, rblock, wgs;
     };
-    auto plan = [&](uint32_t nbuckets) {
-        Plan p;
-        // (wide windows have 16-32 times the buckets: with 2^19 per window even a lone call fills the chip many times over at
-        // L = 8, and what counts is again the instruction volume -- n = 2^24, c = 20: reduction 8.6 ms at L = 8, 4.6 at L = 128,
-        // profiles/r02_reduce_l_wide_windows.txt -- hence the same rule with a cap of 128 instead of a fixed 8)
-        const uint32_t wide_cap = g.c > 16 ? 128u : (others_pending ? 32u : 8u);
-        p.L = others_pending ? std::min(wide_cap, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
-                             : std::min(wide_cap * lanes_per_point<FK>(), std::max(1u, (uint32_t)(((uint64_t)nbuckets * lanes_per_point<FK>() + 65535u) / 65536u)));
-        // a power of two (the nearer one): a lane multiplies its run by its first index t*L with double-and-add, and the zero low
-        // bits of that index cost no additions (sharded calls: L = 10 -> 8 took 1.25 -> 1.17 ms per call at 4 ranks, 18 -> 16 1.62 -> 1.56 at 2)
-        {
-            uint32_t f = 1;
-            while (f * 2 <= p.L) f *= 2;
-            p.L = (2 * p.L >= 3 * f) ? 2 * f : f;
-        }
-        if (ctx->force_L) p.L = ctx->force_L;   // (a power of two: msm_amd_set_option rejects anything else -- the LDS trees halve)
-        p.lanes = (g.half + p.L - 1) / p.L;
-        p.rblock = std::min(256u, std::max(64u, p.lanes));
-        while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
-        p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
-        return p;
+    struct Shape {
+        Plan p0, p1;
+        bool planes;
+        uint32_t planes_L, planes_mlog;
     };
-    Plan p0 = plan(split), p1 = plan(NB - split);
-    // Round 4: the reduction as plain sums (k_bucket_planes: no double-and-add on the GPU, the host's Horner pass applies the weights;
-    // one wave is the unit of work).  Buckets per lane: a lone call wants one wave per SIMD and the shortest chain (2L + 7 additions, then
-    // the window's 6); small calls in flight the same, their slots wait for this chain (n = 2^16, three in flight, L = 2 | 4 | 8 | 16:
-    // 0.463 | 0.415 | 0.438 | 0.501 ms per call; k_bucket_reduce 0.484).  The large pipelined calls keep k_bucket_reduce: their reduction waits
-    // for register room beside the next call's accumulation either way, and two launches wait twice (G1, n = 2^20: 2.65 against 2.55 ms for
-    // BLS12-381, 1.42 against 1.35 for BN254; from n = 2^22 on, and for G2, the plane kernels win again: 10.6 against 10.8 ms, 2.56 against 2.68).
-    uint32_t planes_mlog = 0, planes_L = 0;
-    // (... as long as that accumulation is the long one: with fewer than 24 entries per bucket on average -- the last call of the same shape
-    // says -- it is not, and the reduction's chain is what a slot waits for: witness-like scalars at n = 2^20, profiles/r04_witness_like_sparse.txt)
-    const bool sparse = ctx->fill_nb.load() == NB && ctx->fill_mean16.load() < 24u * 16u;
-    // (windows above 16 bits, other calls in flight: k_bucket_reduce as well -- n = 2^23, c = 19: 19.3 against 21.5 ms per call; c = 20 even)
-    const bool planes_hidden = others_pending && !sparse &&
-                               (g.c > 16 || ((uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1));
-    bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && g.half >= 256;
-    if (planes) {
-        const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
-        uint32_t L = std::max(4u, others_pending && g.c <= 16 ? (sparse ? std::min(8u, p0.L / 2) : p0.L / 2) : p0.L);
-        if (ctx->force_L) L = std::max(2u, ctx->force_L);
-        while (L > 2 && g.half / L < lpw) L /= 2;
-        // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
-        const uint32_t L_rule = L;
-        while (g.half / (L * lpw) > 4 * lpw) L *= 2;
-        // (a single very wide window -- the merged windows of a prepared table at n = 2^20 -- would need running sums four times as long as
-        // k_bucket_reduce's rule gives it: that kernel's chain is the shorter one there, latency 3.08 against 3.68 ms)
-        if (L > 2 * L_rule && ctx->reduce_planes != 2) planes = false;
-        if (L > 256) planes = false;
-        planes_L = L;
-        for (planes_mlog = 0; ((uint64_t)L * lpw << planes_mlog) < g.half; ++planes_mlog) {}
+    // (the shape of the reduction is a function of whether other calls are in flight; a slot sizes its buffers for both forms below)
+    auto shape_for = [&](bool pending) -> Shape {
+        auto plan = [&](uint32_t nbuckets) {
+            Plan p;
+            // (wide windows have 16-32 times the buckets: with 2^19 per window even a lone call fills the chip many times over at
+            // L = 8, and what counts is again the instruction volume -- n = 2^24, c = 20: reduction 8.6 ms at L = 8, 4.6 at L = 128,
+            // profiles/r02_reduce_l_wide_windows.txt -- hence the same rule with a cap of 128 instead of a fixed 8)
+            const uint32_t wide_cap = g.c > 16 ? 128u : (pending ? 32u : 8u);
+            p.L = pending ? std::min(wide_cap, std::max(1u, (uint32_t)(((uint64_t)g.Wl * g.half) / 16384u)))
+                                 : std::min(wide_cap * lanes_per_point<FK>(), std::max(1u, (uint32_t)(((uint64_t)nbuckets * lanes_per_point<FK>() + 65535u) / 65536u)));
+            // a power of two (the nearer one): a lane multiplies its run by its first index t*L with double-and-add, and the zero low
+            // bits of that index cost no additions (sharded calls: L = 10 -> 8 took 1.25 -> 1.17 ms per call at 4 ranks, 18 -> 16 1.62 -> 1.56 at 2)
+            {
+                uint32_t f = 1;
+                while (f * 2 <= p.L) f *= 2;
+                p.L = (2 * p.L >= 3 * f) ? 2 * f : f;
+            }
+            if (ctx->force_L) p.L = ctx->force_L;   // (a power of two: msm_amd_set_option rejects anything else -- the LDS trees halve)
+            p.lanes = (g.half + p.L - 1) / p.L;
+            p.rblock = std::min(256u, std::max(64u, p.lanes));
+            while ((size_t)p.rblock * BSZ > 64 * 1024 && p.rblock > 64) p.rblock /= 2;   // LDS budget (64 KB default limit)
+            p.wgs = (p.lanes + p.rblock - 1) / p.rblock;
+            return p;
+        };
+        Plan p0 = plan(split), p1 = plan(NB - split);
+        // Round 4: the reduction as plain sums (k_bucket_planes: no double-and-add on the GPU, the host's Horner pass applies the weights;
+        // one wave is the unit of work).  Buckets per lane: a lone call wants one wave per SIMD and the shortest chain (2L + 7 additions, then
+        // the window's 6); small calls in flight the same, their slots wait for this chain (n = 2^16, three in flight, L = 2 | 4 | 8 | 16:
+        // 0.463 | 0.415 | 0.438 | 0.501 ms per call; k_bucket_reduce 0.484).  The large pipelined calls keep k_bucket_reduce: their reduction waits
+        // for register room beside the next call's accumulation either way, and two launches wait twice (G1, n = 2^20: 2.65 against 2.55 ms for
+        // BLS12-381, 1.42 against 1.35 for BN254; from n = 2^22 on, and for G2, the plane kernels win again: 10.6 against 10.8 ms, 2.56 against 2.68).
+        uint32_t planes_mlog = 0, planes_L = 0;
+        // (... as long as that accumulation is the long one: with fewer than 24 entries per bucket on average -- the last call of the same shape
+        // says -- it is not, and the reduction's chain is what a slot waits for: witness-like scalars at n = 2^20, profiles/r04_witness_like_sparse.txt)
+        const bool sparse = ctx->fill_nb.load() == NB && ctx->fill_mean16.load() < 24u * 16u;
+        // (windows above 16 bits, other calls in flight: k_bucket_reduce as well -- n = 2^23, c = 19: 19.3 against 21.5 ms per call; c = 20 even)
+        const bool planes_hidden = pending && !sparse &&
+                                   (g.c > 16 || ((uint64_t)g.Wl * g.half >= (1u << 19) && a.n < (1u << 21) && lanes_per_point<FK>() == 1));
+        bool planes = ctx->reduce_planes && (ctx->reduce_planes == 2 || !planes_hidden) && g.half >= 256;
         if (planes) {
-            p0.L = L;
-            p0.wgs = 1 + kl + planes_mlog;   // partials per window
-            p1 = p0;                         // (a split call: both window groups the same way)
+            const uint32_t kl = planes_lane_bits<FK>(), lpw = 1u << kl;
+            uint32_t L = std::max(4u, pending && g.c <= 16 ? (sparse ? std::min(8u, p0.L / 2) : p0.L / 2) : p0.L);
+            if (ctx->force_L) L = std::max(2u, ctx->force_L);
+            while (L > 2 && g.half / L < lpw) L /= 2;
+            // the window's second stage is one wave per value, every lane adding up at most four of the window's waves first
+            const uint32_t L_rule = L;
+            while (g.half / (L * lpw) > 4 * lpw) L *= 2;
+            // (a single very wide window -- the merged windows of a prepared table at n = 2^20 -- would need running sums four times as long as
+            // k_bucket_reduce's rule gives it: that kernel's chain is the shorter one there, latency 3.08 against 3.68 ms)
+            if (L > 2 * L_rule && ctx->reduce_planes != 2) planes = false;
+            if (L > 256) planes = false;
+            planes_L = L;
+            for (planes_mlog = 0; ((uint64_t)L * lpw << planes_mlog) < g.half; ++planes_mlog) {}
+            if (planes) {
+                p0.L = L;
+                p0.wgs = 1 + kl + planes_mlog;   // partials per window
+                p1 = p0;                         // (a split call: both window groups the same way)
+            }
         }
-    }
+        return Shape{p0, p1, planes, planes_L, planes_mlog};
+    };
+    const Shape shape = shape_for(others_pending), other_shape = shape_for(!others_pending);
+    Plan p0 = shape.p0, p1 = shape.p1;
+    const bool planes = shape.planes;
+    const uint32_t planes_L = shape.planes_L, planes_mlog = shape.planes_mlog;
     const uint32_t nparts0 = w_split * p0.wgs, nparts1 = (g.Wl - w_split) * p1.wgs, nparts = nparts0 + nparts1;
     sl->part_off.assign(g.Wl, 0);
     sl->part_cnt.assign(g.Wl, 0);
@@ -940,18 +953,27 @@ int MsmCall<F>::reduce() {
         sl->part_cnt[wl] = wl < w_split ? p0.wgs : p1.wgs;
     }
     sl->plane_shift = -1;
-    if (planes) {
+    if (planes)
         for (sl->plane_shift = 0; (1u << sl->plane_shift) < planes_L; ++sl->plane_shift) {}
-        if (planes_mlog)
-            if (int rc = ensure(ctx, sl->d_planes, ((size_t)g.Wl << planes_mlog) * (planes_lane_bits<FK>() + 2) * BSZ)) return rc;
-    }
-    if (int rc = ensure(ctx, sl->d_partials, (size_t)nparts * XSZ + 64)) return rc;   // the partials, then the eight tail words (k_collect_tail)
-    if (sl->h_partials_cap < (size_t)nparts * XSZ + 64) {
+    // The buffers take the larger of the two forms' needs, whichever form this call runs: a slot that had only seen calls with others in
+    // flight used to free and allocate again on its first lone call (three times the partials, the plane sums) -- and a free waits for
+    // the device, i.e. for this very call's accumulation: the first of the driver's 20 timed calls after 5 warmup calls lands on such a slot,
+    // and its successor was submitted 3 ms late (profiles/r04_fill_drain_before.txt).
+    auto planes_bytes = [&](const Shape& sh) { return sh.planes && sh.planes_mlog ? ((size_t)g.Wl << sh.planes_mlog) * (planes_lane_bits<FK>() + 2) * BSZ : (size_t)0; };
+    auto parts_of = [&](const Shape& sh) { return (size_t)g.Wl * std::max(sh.p0.wgs, sh.p1.wgs); };
+    // (the other form is evaluated on this call's window groups, and a lone call may split them differently: twice its figure covers that;
+    // these buffers are small -- n = 2^20: 78 KB of plane sums, 22 KB of partials)
+    const size_t planes_need = std::max(planes_bytes(shape), 2 * planes_bytes(other_shape));
+    const size_t parts_need = std::max((size_t)nparts, 2 * parts_of(other_shape));
+    if (planes_need)
+        if (int rc = ensure(ctx, sl->d_planes, planes_need)) return rc;
+    if (int rc = ensure(ctx, sl->d_partials, parts_need * XSZ + 64)) return rc;   // the partials, then the eight tail words (k_collect_tail)
+    if (sl->h_partials_cap < parts_need * XSZ + 64) {
         if (sl->h_partials) HIPCHK(ctx, hipHostFree(sl->h_partials));
         sl->h_partials = nullptr;
         sl->h_partials_cap = 0;
-        HIPCHK(ctx, hipHostMalloc(&sl->h_partials, (size_t)nparts * XSZ * 2 + 64, hipHostMallocDefault));
-        sl->h_partials_cap = (size_t)nparts * XSZ * 2 + 64;
+        HIPCHK(ctx, hipHostMalloc(&sl->h_partials, parts_need * XSZ * 2 + 64, hipHostMallocDefault));
+        sl->h_partials_cap = parts_need * XSZ * 2 + 64;
     }
     uint8_t* partials = ctx->zero_copy ? (uint8_t*)sl->h_partials : (uint8_t*)sl->d_partials.p;
     HIPCHK(ctx, hipStreamWaitEvent(sb, sl->ev[8], 0));
