@@ -470,3 +470,50 @@ def test_reduction_follows_the_reported_density(orc):
         assert [t.wait() for t in ts] == [exp, exp]
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("curve,group,n", [("bls12381", 1, 6000), ("bn128", 1, 9000), ("bls12381", 2, 2500), ("bn128", 2, 3000)])
+def test_deferred_reduction_in_bursts_and_alone(orc, curve, group, n):
+    """Option defer_reduce (csrc/engine_call.hpp, submit_msm): a call in a stream of calls leaves its bucket reduction
+    (wasmcurves/src/build_multiexp.js:120-184, reduceTable) to the next submission or to the wait for its own ticket, which also picks the
+    reduction's form.  16-bit windows put the accumulation on the context's shared stream at any n, the regime the deferral applies to.
+    (G2 calls are never deferred: their cases run the same sequences on the undeferred path.)
+    Every order of submissions and waits must give the oracle's bytes, with the option on and off."""
+    import msm_amd
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_window_bits(16)
+        eng.set_option("slots", 3)
+        C = eng.curve(curve)
+        O = orc.Oracle(curve, group)
+        asz = len(gu.random_case(curve, group, "probe", 1)[0])
+        bases, scalars = gu.random_case(curve, group, f"gpu:defer:{curve}:{group}:{n}", n)
+        m = n // 3
+        exp = O.normalize(O.multiexp_affine(bases, scalars, 32, n))
+        exp_m = O.normalize(O.multiexp_affine(bases[:m * asz], scalars[:32 * m], 32, m))
+        sync = _f(C, group)
+        for defer in (1, 0, 1):
+            eng.set_option("defer_reduce", defer)
+            assert sync(bases, scalars, 32, n) == exp                      # a lone call before any burst
+            # a burst of three, waited for newest first: the newest one's reduction is queued by its own wait with two older calls in flight
+            t1, t2, t3 = C.multiexp_async(group, bases, scalars, 32, n), C.multiexp_async(group, bases[:m * asz], scalars[:32 * m], 32, m), C.multiexp_async(group, bases, scalars, 32, n)
+            assert t3.wait() == exp and t1.wait() == exp and t2.wait() == exp_m
+            # the first call after a burst is deferred although nothing is in flight (the context has seen a burst lately): alone, then followed
+            assert sync(bases[:m * asz], scalars[:32 * m], 32, m) == exp_m
+            t1 = C.multiexp_async(group, bases, scalars, 32, n)
+            t2 = C.multiexp_async(group, bases[:m * asz], scalars[:32 * m], 32, m)    # queues t1's reduction in the hidden form
+            assert t1.wait() == exp
+            t3 = C.multiexp_async(group, bases, scalars, 32, n)
+            assert t2.wait() == exp_m and t3.wait() == exp
+            # a steady stream, two in flight, and then enough lone calls to run the context's memory of the burst down
+            fl, got = [], []
+            for i in range(7):
+                fl.append(C.multiexp_async(group, bases, scalars, 32, n))
+                if len(fl) == 2:
+                    got.append(fl.pop(0).wait())
+            got += [t.wait() for t in fl]
+            assert all(g == exp for g in got)
+            for i in range(10):
+                assert sync(bases[:m * asz], scalars[:32 * m], 32, m) == exp_m
+    finally:
+        eng.close()

@@ -116,16 +116,30 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         msm_set_err(ctx, "every slot of this context holds an uncollected call: wait for an older ticket first");
         return MSM_AMD_EINVAL;
     }
+    // reductions that were left for "the next thing that happens on the context" (engine_call.hpp, submit_msm): this submission is that
+    // thing -- they go first, in the form that hides behind an accumulation.  A failure is kept for the wait on that ticket.
+    for (uint32_t k = 0; k < ctx->nslots; ++k) {
+        Slot* o = &ctx->slots[k];
+        if (o != sl && o->pending && o->deferred_reduce)
+            if (int drc = flush_deferred_reduce(ctx, o, true)) o->deferred_rc = drc;
+    }
+    sl->deferred_rc = 0;
+    {
+        RunArgs kept = a;       // (`a` may be this very slot's copy: the collector's second run of a call)
+        sl->retry_args = kept;  // the slot's copy outlives the submission: a deferred reduction reads it
+    }
+    const RunArgs& as = sl->retry_args;
     int rc;
-    if (curve == MSM_AMD_BLS12381 && group == 1) rc = submit_msm<Fp<Bls12381Fp>>(ctx, sl, a);
-    else if (curve == MSM_AMD_BLS12381 && group == 2) rc = submit_msm<Fp2<Bls12381Fp>>(ctx, sl, a);
-    else if (curve == MSM_AMD_BN128 && group == 1) rc = submit_msm<Fp<Bn254Fp>>(ctx, sl, a);
-    else if (curve == MSM_AMD_BN128 && group == 2) rc = submit_msm<Fp2<Bn254Fp>>(ctx, sl, a);
+    if (curve == MSM_AMD_BLS12381 && group == 1) rc = submit_msm<Fp<Bls12381Fp>>(ctx, sl, as);
+    else if (curve == MSM_AMD_BLS12381 && group == 2) rc = submit_msm<Fp2<Bls12381Fp>>(ctx, sl, as);
+    else if (curve == MSM_AMD_BN128 && group == 1) rc = submit_msm<Fp<Bn254Fp>>(ctx, sl, as);
+    else if (curve == MSM_AMD_BN128 && group == 2) rc = submit_msm<Fp2<Bn254Fp>>(ctx, sl, as);
     else {
         msm_set_err(ctx, "unknown curve/group");
         return MSM_AMD_EINVAL;
     }
     if (rc) {
+        sl->deferred_reduce = nullptr;
         sl->binhist_zero.clear();   // whatever the sort had counted so far is not to be trusted
         sl->ctl_zero.clear();
         sl->flags_zero.clear();
@@ -138,7 +152,6 @@ static int submit(msm_amd_ctx* ctx, int curve, int group, const RunArgs& a, uint
         return rc;
     }
     sl->pending = true;
-    sl->retry_args = a;
     sl->retry_curve = curve;
     sl->retry_group = group;
     sl->prepared = a.prepared;
@@ -164,6 +177,30 @@ static int finish_ticket(msm_amd_ctx* ctx, uint64_t ticket, uint8_t* out) {
         if (!found) {
             msm_set_err(ctx, "unknown or already collected ticket");
             return MSM_AMD_EINVAL;
+        }
+        // nothing was submitted after this call: its reduction is queued now, in the form the moment asks for
+        if (found->deferred_reduce) {
+            bool others = false;
+            for (Slot& sl : ctx->slots) others |= (&sl != found && sl.pending);
+            found->deferred_rc = flush_deferred_reduce(ctx, found, others);
+        }
+        if (found->deferred_rc) {   // the reduction could not be queued (out of memory, a HIP failure): the call is over, the slot free
+            const int drc = found->deferred_rc;
+            found->deferred_rc = 0;
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(found->stream_c);
+            (void)hipStreamSynchronize(found->stream_b);
+            found->ctl_zero.clear();
+            found->flags_zero.clear();
+            if (found->prepared) {
+                found->prepared->in_flight.fetch_sub(1);
+                found->prepared = nullptr;
+            }
+            found->pending = false;
+            found->collecting = false;
+            found->sync_owned = false;
+            ctx->cv.notify_all();
+            return drc;
         }
     }
     // wait for the GPU outside the lock (other threads may submit and collect meanwhile)
@@ -515,6 +552,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->force_L = value;
         return 0;
     }
+    if (!strcmp(name, "defer_reduce")) { ctx->defer_reduce = value ? 1 : 0; return 0; }
     if (!strcmp(name, "reduce_planes")) { ctx->reduce_planes = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "reduce_pair")) { ctx->reduce_pair = value != 0; return 0; }

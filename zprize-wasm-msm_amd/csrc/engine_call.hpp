@@ -7,6 +7,7 @@
 //   finish_msm<F>      stage 6 on the host: window sums, Horner combine, normalisation, the hints for the context's next calls
 // What the reference does here in one loop nest: wasmcurves/src/build_multiexp.js:251-371 (schedule), :96-249 (one window).
 #pragma once
+#include <memory>
 #include "engine_ctx.hpp"
 #include "sort_kernels.hpp"
 
@@ -169,7 +170,7 @@ struct MsmCall {
     Slot* sl;
     const RunArgs& a;
     const size_t BSZ = bucket_bytes<FK>();   // one bucket in HBM
-    bool others_pending = false, use_glv = false, split_mode = false;
+    bool others_pending = false, use_glv = false, split_mode = false, acc_shared = false;   // (acc_shared: the accumulation runs on the context's stream A)
     hipStream_t st = nullptr;                // the stream the current stage queues on
     const uint8_t *d_bases = nullptr, *d_scalars = nullptr, *d_xbeta = nullptr;
     Geom g{};
@@ -188,10 +189,40 @@ struct MsmCall {
 template <class F>
 static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     MsmCall<F> call(ctx, sl, a);
+    sl->deferred_reduce = nullptr;
     if (int rc = call.plan()) return rc == MsmCall<F>::kNothingToQueue ? 0 : rc;
     if (int rc = call.sort()) return rc;
     if (int rc = call.accumulate()) return rc;
+    // The reduction has two forms (reduce()): one that hides behind the next call's accumulation, one for a call that nothing follows.
+    // Which of them is right is not known here: the first call of a burst looks lone, the last one looks followed (the driver's 20 timed
+    // calls: the first reduction, two launches of the lone form, waited 2.4 ms for register room beside the second accumulation and held up
+    // the third submission; the last one ran its long hidden form alone, 1.30 ms where the lone form takes 0.58 --
+    // profiles/r04_fill_drain_after_buffers.txt).  So a call in a stream of calls -- others in flight now, or lately -- with its
+    // accumulation on stream A leaves its reduction to flush_deferred_reduce(): at the next submission, before that call's kernels,
+    // or at the wait for its own ticket, whichever comes first.  (`a` is the slot's copy of the arguments: it lives as long as the call.)
+    const bool streaming = call.others_pending || ctx->burst_hint > 0;
+    if (call.others_pending) ctx->burst_hint = 8;
+    else if (ctx->burst_hint > 0) --ctx->burst_hint;
+    // (G1 only: a G2 call's reduction is the longer one, and its successor's submission -- which waits for the call before -- came too late
+    // for it: BLS12-381 G2 n = 2^20, 20 calls: 8.11 against 7.79 ms per call, profiles/r04_defer_reduce_ab.txt)
+    if (ctx->defer_reduce && streaming && call.acc_shared && !call.split_mode && lanes_per_point<typename MsmCall<F>::FK>() == 1 && &a == &sl->retry_args) {
+        auto keep = std::make_shared<MsmCall<F>>(call);
+        sl->deferred_reduce = [keep](bool pending) {
+            keep->others_pending = pending;
+            return keep->reduce();
+        };
+        return 0;
+    }
     return call.reduce();
+}
+
+// Queue a slot's deferred reduction, if it has one (ctx->mu held).  `pending`: other calls are in flight at this moment.
+static inline int flush_deferred_reduce(msm_amd_ctx* ctx, Slot* sl, bool pending) {
+    if (!sl->deferred_reduce) return 0;
+    std::function<int(bool)> f = std::move(sl->deferred_reduce);
+    sl->deferred_reduce = nullptr;
+    (void)hipSetDevice(ctx->device);
+    return f(pending);
 }
 
 // ---- the call's plan: inputs on the GPU, window layout, schedule, limits, the slot's tables
@@ -760,6 +791,7 @@ int MsmCall<F>::accumulate() {
     const uint32_t k_first = lanes_per_bucket(split), k_second = split < NB ? lanes_per_bucket(NB - split) : 1u;
     const bool small_acc = ctx->acc_stream ? ctx->acc_stream == 1 : (NB < 5u * 1024u * 64u && !split_mode);
     st = small_acc ? sl->stream_b : ctx->stream;   // (the slot's B stream: its reduction follows on the same stream anyway)
+    acc_shared = !small_acc;
     HIPCHK(ctx, hipStreamWaitEvent(st, sl->ev[4], 0));
     HIPCHK(ctx, hipEventRecord(sl->ev[9], st));
     // segment length: mean bucket population + 8 standard deviations of a Poisson bucket, at least 32: random inputs

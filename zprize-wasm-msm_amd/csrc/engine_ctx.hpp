@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <map>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -97,6 +98,8 @@ struct Slot {
     msm_amd_bases* prepared = nullptr;   // the call runs on a prepared table (released from in_flight when collected)
     DevBuf d_flags;                      // word 0: a scalar had bits beyond the windows of the prepared table
     int (*finish)(msm_amd_ctx*, Slot*, uint8_t*) = nullptr;
+    int deferred_rc = 0;                        // what queueing the deferred reduction returned, for the wait on the ticket
+    std::function<int(bool)> deferred_reduce;   // the call's reduction, not queued yet (argument: are other calls in flight now?); under ctx->mu
     RunArgs retry_args{};            // what was submitted, kept so that the collector can run the call again (narrow layout met a wide scalar)
     int retry_curve = 0, retry_group = 0;
     DevBuf* bufs[27] = {&d_planes, &d_itab, &d_flags, &d_slices, &d_xbeta, &d_halves, &d_tmp, &d_binhist, &d_binstart, &d_bincur, &d_cpre, &d_desc, &d_bcursor, &d_tailctl, &d_work, &d_biglist, &d_segout, &d_bases, &d_scalars,
@@ -196,6 +199,11 @@ struct msm_amd_ctx {
     // count takes it as the expected density of its own input (reduce(): sparse inputs -- a witness full of zeros, ones and small values --
     // have a short accumulation that cannot hide a long reduction)
     std::atomic<uint32_t> fill_nb{0}, fill_mean16{0};
+    // option "defer_reduce" (1): the reduction of a call that takes part in a stream of calls is queued when the next thing happens on the
+    // context -- the next submission (it will hide behind that call's accumulation: the form for that) or the wait for its own ticket (nothing
+    // followed: the lone form, less than half as long) -- instead of at its own submission, where the engine can only guess (engine_call.hpp)
+    int defer_reduce = 1;
+    int burst_hint = 0;      // > 0: calls were submitted with others in flight lately (8 at such a submission, one less at every other one)
     int reduce_planes = 1;   // option "reduce_planes": the bucket reduction as plain sums (k_bucket_planes): 1 = where it pays (reduce()), 2 = wherever it can, 0 = k_bucket_reduce always
     uint32_t force_L = 0;   // MSM_AMD_REDUCE_L: buckets per lane in k_bucket_reduce (tuning)
     int no_hot = 0;         // option "hot" = 0: no short segments / grouped fold for hot buckets
