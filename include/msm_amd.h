@@ -116,11 +116,11 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
  *   reduce_l         buckets per lane of the bucket reduction (a power of two)
  *   reduce_planes    the bucket reduction as plain sums whose weights the host's Horner pass applies (k_bucket_planes): 1 (default) where it
  *                    pays, 2 wherever it can, 0 never (k_bucket_reduce: running sums + a double-and-add per lane)
- *   defer_reduce     1 (default): a call that is part of a stream of calls (others in flight at its submission, or lately) with a full-size
+ *   defer_reduce     1 (default): a G1 call that is part of a stream of calls (others in flight at its submission, or lately) with a full-size
  *                    accumulation has its reduction queued by the next submission on the context (in the form that hides behind that call's
  *                    accumulation) or by the wait for its own ticket (nothing followed: the short lone form) -- so such a call only
  *                    completes once one of the two has happened: wait for tickets, do not poll for them.  0: every reduction is queued at
- *                    submission, in the form the calls in flight at that moment suggest
+ *                    submission, in the form the calls in flight at that moment suggest.  2: G2 calls are deferred too (measured: slower)
  *
  *   -- experiments that were measured and left off, kept for re-measurement ---------------------------------------------------------
  *   split (1 = reduce a lone call's windows in two overlapping groups: slower), reduce_pair (1 = the G1 reduction on lane pairs: no gain),

@@ -552,7 +552,7 @@ int msm_amd_set_option(msm_amd_ctx* ctx, const char* name, uint32_t value) {
         ctx->force_L = value;
         return 0;
     }
-    if (!strcmp(name, "defer_reduce")) { ctx->defer_reduce = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "defer_reduce")) { ctx->defer_reduce = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "reduce_planes")) { ctx->reduce_planes = value > 2 ? 2 : (int)value; return 0; }
     if (!strcmp(name, "split")) { ctx->no_split = value == 0; return 0; }
     if (!strcmp(name, "reduce_pair")) { ctx->reduce_pair = value != 0; return 0; }

@@ -203,9 +203,10 @@ static int submit_msm(msm_amd_ctx* ctx, Slot* sl, const RunArgs& a) {
     const bool streaming = call.others_pending || ctx->burst_hint > 0;
     if (call.others_pending) ctx->burst_hint = 8;
     else if (ctx->burst_hint > 0) --ctx->burst_hint;
-    // (G1 only: a G2 call's reduction is the longer one, and its successor's submission -- which waits for the call before -- came too late
-    // for it: BLS12-381 G2 n = 2^20, 20 calls: 8.11 against 7.79 ms per call, profiles/r04_defer_reduce_ab.txt)
-    if (ctx->defer_reduce && streaming && call.acc_shared && !call.split_mode && lanes_per_point<typename MsmCall<F>::FK>() == 1 && &a == &sl->retry_args) {
+    // (G1 only: a G2 call's reduction is the longer one, and its successor's submission -- which waits for the call before -- comes too late
+    // for it: BLS12-381 G2 n = 2^20: 8.06-8.10 against 7.73-7.79 ms per call over 20 calls, the same over 60; BN254 G2 no difference --
+    // profiles/r04_defer_reduce_g2_ab.txt.  Option value 2 defers them too.)
+    if (ctx->defer_reduce && streaming && call.acc_shared && !call.split_mode && (lanes_per_point<typename MsmCall<F>::FK>() == 1 || ctx->defer_reduce == 2) && &a == &sl->retry_args) {
         auto keep = std::make_shared<MsmCall<F>>(call);
         sl->deferred_reduce = [keep](bool pending) {
             keep->others_pending = pending;
