@@ -419,8 +419,13 @@ int msm_amd_create(int device_id, msm_amd_ctx** out_ctx) {
     if (const char* e = getenv("MSM_AMD_SEG")) ctx->force_seg = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_C")) ctx->force_c = (uint32_t)atoi(e);
     if (const char* e = getenv("MSM_AMD_DIST_TIMEOUT_MS")) ctx->dist_timeout_ms.store((uint32_t)strtoul(e, nullptr, 10));
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_s, hipStreamNonBlocking) != hipSuccess) {
+    // (experiments: MSM_AMD_S_PRIORITY / MSM_AMD_A_PRIORITY create the sort stream / the accumulation stream at that HIP priority, -1 = greatest)
+    auto make_stream = [](hipStream_t* st, const char* env) {
+        const char* e = getenv(env);
+        return e ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, atoi(e)) : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    if (hipSetDevice(device_id) != hipSuccess || make_stream(&ctx->stream, "MSM_AMD_A_PRIORITY") != hipSuccess ||
+        make_stream(&ctx->stream_s, "MSM_AMD_S_PRIORITY") != hipSuccess) {
         delete ctx;
         return MSM_AMD_EHIP;
     }
