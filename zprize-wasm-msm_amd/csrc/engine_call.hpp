@@ -631,6 +631,9 @@ int MsmCall<F>::sort() {
     if (!sl->flags_zero.holds(sl->d_flags)) HIPCHK(ctx, hipMemsetAsync(sl->d_flags.p, 0, 16, st));
     sl->flags_zero.clear();   // until this submission has got as far as k_collect_tail
 #define MSM_TILE_HIST(NW, BL) k_tile_hist<NW, 4, BL><<<ntile, BL, hist_lds, st>>>(d_items, g, sg, binhist, (uint32_t*)sl->d_flags.p)
+    // (one-wave workgroups for the histogram of a call that runs beside another call's accumulation -- a 256-lane workgroup needs a wave slot
+    // on all four SIMDs of a CU at once, the accumulation refills slots singly -- were tried: the next accumulation starts 45 us sooner, and
+    // the running one loses 230 us to the waves that took its slots: 2.71-2.75 against 2.55-2.58 ms per MSM, profiles/r04_hist_one_wave_tried.txt)
     if (wide) {
         if (nw == 8) MSM_TILE_HIST(8, 1024);
         else if (nw == 4) MSM_TILE_HIST(4, 1024);
