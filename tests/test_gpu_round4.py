@@ -517,3 +517,42 @@ def test_deferred_reduction_in_bursts_and_alone(orc, curve, group, n):
                 assert sync(bases[:m * asz], scalars[:32 * m], 32, m) == exp_m
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14] + [int(s) for s in os.environ.get("MSM_TEST_EXTRA_SEEDS", "").split(",") if s.strip()])
+def test_deferred_reduction_under_random_orders_of_submissions_and_waits(orc, seed):
+    """Seeded sequences of asynchronous submissions (three sizes, G1 of both curves on one context, up to three in flight), waits for a
+    randomly chosen ticket, synchronous calls in between and changes of option defer_reduce: whichever call's reduction is queued by whichever
+    event (the next submission, its own wait with older or no calls in flight), every result is the oracle's."""
+    import msm_amd
+    rnd = random.Random(seed)
+    eng = msm_amd.Engine(0)
+    try:
+        eng.set_window_bits(16)
+        eng.set_option("slots", 3)
+        cases = []
+        for curve in ("bls12381", "bn128"):
+            C, O = eng.curve(curve), orc.Oracle(curve, 1)
+            asz = len(gu.random_case(curve, 1, "probe", 1)[0])
+            for n in (700, 2500, 5000):
+                b, s = gu.random_case(curve, 1, f"gpu:defer-rnd:{curve}:{n}:{seed}", n)
+                cases.append((C, b, s, n, O.normalize(O.multiexp_affine(b, s, 32, n))))
+        flying = []
+        for step in range(60):
+            r = rnd.random()
+            if r < 0.05:
+                eng.set_option("defer_reduce", rnd.choice((0, 1, 2)))
+            elif r < 0.15 and len(flying) < 3:
+                C, b, s, n, exp = rnd.choice(cases)
+                assert C.g1m_multiexpAffine(b, s, 32, n) == exp
+            elif r < 0.65 and len(flying) < 3:
+                C, b, s, n, exp = rnd.choice(cases)
+                flying.append((C.multiexp_async(1, b, s, 32, n), exp))
+            elif flying:
+                t, exp = flying.pop(rnd.randrange(len(flying)))
+                assert t.wait() == exp
+        while flying:
+            t, exp = flying.pop(rnd.randrange(len(flying)))
+            assert t.wait() == exp
+    finally:
+        eng.close()
