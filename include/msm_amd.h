@@ -78,7 +78,8 @@ int msm_amd_set_window_bits(msm_amd_ctx *ctx, uint32_t c);
 /* Options of a context (msm_amd_set_option; 0 = automatic unless stated).  Environment: MSM_AMD_C, MSM_AMD_SEG, MSM_AMD_REDUCE_L
  * (= window_bits, segment, reduce_l at create), MSM_AMD_DIST_TIMEOUT_MS, MSM_AMD_RCCL_LIB (the collective library of a multi-GPU
  * group, default librccl.so.1), MSM_AMD_NO_CALIBRATE (keep the streams in creation order), MSM_AMD_DEBUG_TAIL (print segment / long
- * bucket / hot bucket counts of every collected call).
+ * bucket / hot bucket counts of every collected call); experiments only: MSM_AMD_S_PRIORITY / MSM_AMD_A_PRIORITY (HIP priority of the sort /
+ * accumulation stream at create; measured: no effect).
  *
  *   -- what a host may want to set -------------------------------------------------------------------------------------------------
  *   slots            calls in flight per context, 1..8 (default 2); each slot owns its scratch: HBM per slot below
